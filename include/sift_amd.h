@@ -1,0 +1,150 @@
+/*
+ * sift_amd.h -- C ABI of the MI355X (gfx950) CRC-32 / container hot path.
+ *
+ * What this replaces.  matta/sift has no FFI, plugin or operator boundary
+ * (SURVEY.md section 8(b)): `mod crc` is private to the sift-persist crate.  The
+ * entry points below are therefore the ones a maintainer WOULD bind if the
+ * crate's private functions were swapped for an accelerator: one entry per
+ * reference function, same argument meaning, same state-in/state-out
+ * convention, same error cases.  Each declaration cites the reference
+ * function it stands in for.  INTEGRATION.md shows the Rust `extern "C"`
+ * block and the two-line patch to crc.rs / container.rs.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, integer status codes; no C++ or torch types.
+ *  - every input byte is read and reduced on the GPU.  The host computes only
+ *    length-dependent constants (x^(8n) mod P).  There is no CPU fallback:
+ *    without a HIP device every compute call returns SIFT_ERR_NO_DEVICE.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - "state" is the running CRC register exactly as the reference keeps it in
+ *    Digest.value (crc.rs:36-53): initial 0xFFFFFFFF, final XOR by the caller
+ *    (or use the sift_digest_* helpers, which do both).
+ */
+#ifndef SIFT_AMD_H
+#define SIFT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+enum {
+    SIFT_OK = 0,
+    /* container.rs:4-18, enum Error */
+    SIFT_ERR_READ = 1,                     /* Error::Read: short input / bad magic / wrong type */
+    SIFT_ERR_WRITE = 2,                    /* Error::Write: output buffer too small */
+    SIFT_ERR_READ_INVALID_CHUNK_SIZE = 3,  /* Error::ReadInvalidChunkSize */
+    SIFT_ERR_WRITE_INVALID_CHUNK_SIZE = 4, /* Error::WriteInvalidChunkSize */
+    SIFT_ERR_READ_CRC_MISMATCH = 5,        /* Error::ReadCrcMismatch */
+    /* errors the reference cannot have (it never leaves the CPU) */
+    SIFT_ERR_NO_DEVICE = 16,               /* no HIP device / device index out of range */
+    SIFT_ERR_HIP = 17,                     /* a HIP runtime call failed */
+    SIFT_ERR_INVALID_ARG = 18              /* NULL pointer with non-zero length, etc. */
+};
+
+/* Human-readable text for a status code (static storage). */
+const char *sift_strerror(int status);
+/* Detail of the last failure on the calling thread (HIP error text), or "". */
+const char *sift_last_error(void);
+
+#define SIFT_HEADER_LEN 9u                               /* container.rs:104 */
+#define SIFT_CHUNK_SIZE_LIMIT (1024u * 1024u * 1024u)    /* container.rs:49  */
+#define SIFT_CRC_INIT 0xFFFFFFFFu                        /* crc.rs:42        */
+
+/* ------------------------------------------------------------ device setup */
+/* Builds the per-device tables and scratch.  Optional: every compute call
+ * initialises its device on first use.  Returns SIFT_OK or SIFT_ERR_*. */
+int sift_init(int device);
+/* Frees everything sift_init allocated on every device. */
+void sift_shutdown(void);
+/* Bytes of device workspace one in-flight sift_crc32_compute_device call
+ * needs when the caller brings its own (see `workspace` below). */
+size_t sift_crc32_workspace_bytes(void);
+
+/* ------------------------------------------------------- crc.rs:28-34 ----
+ * fn compute(crc: u32, buf: &[u8]) -> u32
+ *
+ * Device-resident input, asynchronous on `stream`.  Reads `len` bytes at
+ * device address `d_buf` (any alignment), starting from running state
+ * `state`, and stores the new running state to device address `d_out`
+ * (4-byte aligned).  If `d_state_in` is non-NULL the starting state is read
+ * from that device word instead of `state` (lets Digest::update calls chain
+ * on a stream with no host round trip).  `workspace` is either NULL (the
+ * library's internal per-device scratch ring is used; calls in flight at the
+ * same time on one device then share a ring of 64 slots) or a device buffer
+ * of sift_crc32_workspace_bytes() that no other in-flight call uses.
+ */
+int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_state_in,
+                              const void *d_buf, uint64_t len, uint32_t *d_out,
+                              void *workspace, void *stream);
+
+/* Same, then waits and returns the new state through `*out` (host). */
+int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf, uint64_t len,
+                                   uint32_t *out, void *stream);
+
+/* Host-resident input: stages `buf` to the device in pipelined pieces (copy
+ * of piece i+1 overlaps the kernel of piece i), reduces it there, returns the
+ * new state through `*out`.  This is the signature the reference's
+ * compute(crc, buf) maps to one-to-one. */
+int sift_crc32_compute_host(int device, uint32_t state, const void *buf, uint64_t len,
+                            uint32_t *out);
+
+/* ------------------------------------------------------- crc.rs:36-53 ----
+ * struct Digest { value: u32 }  /  new / update / finalize                  */
+typedef struct sift_digest {
+    uint32_t value;
+    int32_t device;
+} sift_digest;
+
+void sift_digest_new(sift_digest *d, int device);                          /* crc.rs:41-43 */
+int sift_digest_update(sift_digest *d, const void *buf, uint64_t len);    /* crc.rs:45-47, host bytes */
+int sift_digest_update_device(sift_digest *d, const void *d_buf, uint64_t len, void *stream);
+uint32_t sift_digest_finalize(const sift_digest *d);                       /* crc.rs:50-52 */
+
+/* ---------------------------------------------------- multi-GPU stitching
+ * a buffer split into contiguous ranges A|B.  Given
+ * state_a = compute(s, A) and state_b0 = compute(0, B), returns
+ * compute(s, A|B) = state_a * x^(8*len_b) + state_b0.  Pure host GF(2)
+ * arithmetic on two words; no reference counterpart (the reference is
+ * single-process). */
+uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b);
+
+/* ------------------------------------------------ container.rs:79-84 -----
+ * Chunk::compute_crc: Digest over chunk_type then data, finalized.
+ * `d_type_and_data` points at the 4 type bytes followed by `data_len` data
+ * bytes, contiguous in device memory (as they are inside a serialized
+ * chunk).  Result (finalized CRC) is stored to `d_out`. */
+int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data_len,
+                          uint32_t *d_out, void *workspace, void *stream);
+
+/* ------------------------------------------- container.rs:104-126 --------
+ * write_header / read_header on byte slices.  Return bytes written/consumed
+ * (9) or -SIFT_ERR_*. */
+int64_t sift_write_header(uint8_t *out, size_t cap);
+int64_t sift_read_header(const uint8_t *in, size_t avail);
+
+/* ------------------------------------------- container.rs:68-77 ----------
+ * Chunk::write: u32 BE length | type | data | u32 BE crc, CRC on the GPU.
+ * Returns bytes written (len + 12) or -SIFT_ERR_*. */
+int64_t sift_write_chunk(int device, const uint8_t chunk_type[4], const uint8_t *data,
+                         uint64_t len, uint8_t *out, size_t cap);
+
+/* ------------------------------------------- container.rs:47-66 ----------
+ * Chunk::read: parses one chunk at `in`, verifies its CRC on the GPU.
+ * On success returns bytes consumed and fills type / offset of data within
+ * `in` / data length; on failure returns -SIFT_ERR_* in the order the
+ * reference raises them (size limit before type/data reads, CRC last). */
+int64_t sift_read_chunk(int device, const uint8_t *in, size_t avail, uint8_t chunk_type[4],
+                        uint64_t *data_off, uint32_t *data_len);
+
+/* ------------------------------------------- container.rs:86-96 ----------
+ * Chunk::expect_type.  SIFT_OK or SIFT_ERR_READ. */
+int sift_expect_type(const uint8_t chunk_type[4], const uint8_t expected[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFT_AMD_H */

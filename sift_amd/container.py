@@ -1,0 +1,104 @@
+"""Host-side mirror of sift-persist/src/container.rs over the C ABI.
+
+Same names and error cases as the reference: `Chunk`, `read_header`,
+`write_header`, `read_chunk`, `write_chunk`, `Error` (container.rs:4-18).
+Readers/writers are byte buffers instead of `impl Read` / `impl Write`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+HEADER = bytes([0x89, 0x53, 0x49, 0x46, 0x54, 0x0D, 0x0A, 0x1A, 0x0A])  # container.rs:104
+
+
+class Error(Exception):
+    """container.rs:4-18.  `.kind` is the reference's variant name."""
+
+    KINDS = {
+        _lib.ERR_READ: "Read",
+        _lib.ERR_WRITE: "Write",
+        _lib.ERR_READ_INVALID_CHUNK_SIZE: "ReadInvalidChunkSize",
+        _lib.ERR_WRITE_INVALID_CHUNK_SIZE: "WriteInvalidChunkSize",
+        _lib.ERR_READ_CRC_MISMATCH: "ReadCrcMismatch",
+    }
+
+    def __init__(self, status: int):
+        self.status = status
+        self.kind = self.KINDS.get(status, "Device")
+        super().__init__(lib.sift_strerror(status).decode())
+
+
+def _raise(neg: int):
+    status = -int(neg)
+    if status in Error.KINDS:
+        raise Error(status)
+    raise _lib.SiftError(status)
+
+
+def _dev(device):
+    return torch.cuda.current_device() if device is None else device
+
+
+@dataclass
+class Chunk:
+    """container.rs:35-45."""
+
+    chunk_type: bytes
+    data: bytes
+
+    def expect_type(self, expected_type: bytes) -> None:
+        """container.rs:86-95."""
+        if lib.sift_expect_type(self.chunk_type, expected_type) != _lib.OK:
+            raise Error(_lib.ERR_READ)
+
+
+def write_header(writer: bytearray) -> None:
+    """container.rs:124-126."""
+    buf = (C.c_uint8 * _lib.HEADER_LEN)()
+    n = lib.sift_write_header(buf, _lib.HEADER_LEN)
+    if n < 0:
+        _raise(n)
+    writer += bytes(buf)
+
+
+def read_header(reader, pos: int = 0) -> int:
+    """container.rs:107-121.  Returns the position after the header."""
+    a = np.frombuffer(reader, dtype=np.uint8)
+    n = lib.sift_read_header(a.ctypes.data + pos if a.size else None, max(a.size - pos, 0))
+    if n < 0:
+        _raise(n)
+    return pos + int(n)
+
+
+def write_chunk(chunk: Chunk, writer: bytearray, device: int | None = None) -> None:
+    """container.rs:68-77 / :134-136."""
+    data = np.frombuffer(chunk.data, dtype=np.uint8)
+    out = np.empty(data.size + 12, dtype=np.uint8)
+    n = lib.sift_write_chunk(_dev(device), bytes(chunk.chunk_type),
+                             data.ctypes.data if data.size else None, data.size,
+                             out.ctypes.data, out.size)
+    if n < 0:
+        _raise(n)
+    writer += out[:n].tobytes()
+
+
+def read_chunk(reader, pos: int = 0, device: int | None = None):
+    """container.rs:47-66 / :129-131.  Returns (Chunk, position after it)."""
+    a = np.frombuffer(reader, dtype=np.uint8)
+    t = (C.c_uint8 * 4)()
+    off = C.c_uint64(0)
+    ln = C.c_uint32(0)
+    avail = max(a.size - pos, 0)
+    n = lib.sift_read_chunk(_dev(device), a.ctypes.data + pos if a.size else None, avail,
+                            t, C.byref(off), C.byref(ln))
+    if n < 0:
+        _raise(n)
+    start = pos + off.value
+    return Chunk(bytes(t), a[start:start + ln.value].tobytes()), pos + int(n)

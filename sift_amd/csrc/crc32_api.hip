@@ -1,0 +1,401 @@
+// crc32_api.hip -- host side of the C ABI declared in include/sift_amd.h:
+// per-device context (tables, scratch ring, staging), launch geometry, and
+// the Digest / compute entry points (reference: sift-persist/src/crc.rs).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sift_amd.h"
+#include "crc32_device.h"
+#include "gf2.h"
+
+namespace sift {
+
+static_assert(kThreads == 1024, "table fill in crc32_tiles_kernel assumes 1024 lanes");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return SIFT_ERR_HIP;
+}
+
+#define SIFT_HIP(call)                                  \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) return fail_hip(e__, #call); \
+    } while (0)
+
+constexpr int kRingSlots = 64;
+constexpr size_t kSlotWords = kMaxGroups + 16;   // residues + one result word (+pad)
+constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
+
+const X2nTable& x2n() {
+    static const X2nTable t = make_x2n_table();
+    return t;
+}
+
+struct DeviceCtx {
+    int device = -1;
+    int groups_max = 0;  // workgroups per launch = CUs (one 132 KiB-LDS workgroup per CU)
+    DeviceTables* d_tabs = nullptr;
+    uint32_t* d_ring = nullptr;  // kRingSlots * kSlotWords
+    unsigned ring_next = 0;
+    // host-input staging (sift_crc32_compute_host)
+    uint8_t* d_stage[2] = {nullptr, nullptr};
+    uint32_t* d_state = nullptr;  // chained running state for staged pieces
+    hipStream_t copy_stream = nullptr, work_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    std::mutex host_path_mutex;
+};
+
+std::mutex g_ctx_mutex;
+std::vector<DeviceCtx*> g_ctx;  // indexed by device
+
+void build_tables(DeviceTables* t) {
+    const uint32_t y = gf2_xpow(x2n(), 8ull * kTileBytes);
+    const uint32_t x32 = gf2_xpow(x2n(), 32);
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t b = 0; b < 256; ++b) {
+            t->Y[k * 256 + b] = gf2_mulmod(b << (8 * k), y);
+            t->X[k * 256 + b] = gf2_mulmod(b << (8 * k), x32);
+        }
+    const uint32_t x128 = gf2_xpow(x2n(), 128);
+    uint32_t p = kOne;
+    for (int tdx = kThreads - 1; tdx >= 0; --tdx) {
+        t->Kt[tdx] = p;
+        p = gf2_mulmod(p, x128);
+    }
+}
+
+int get_ctx(int device, DeviceCtx** out) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_last_error = std::string("hipGetDeviceCount: ") +
+                       (e != hipSuccess ? hipGetErrorString(e) : "no devices");
+        return SIFT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_last_error = "device index out of range";
+        return SIFT_ERR_NO_DEVICE;
+    }
+    if ((int)g_ctx.size() < count) g_ctx.resize(count, nullptr);
+    if (g_ctx[device]) {
+        *out = g_ctx[device];
+        return SIFT_OK;
+    }
+    int prev = 0;
+    SIFT_HIP(hipGetDevice(&prev));
+    SIFT_HIP(hipSetDevice(device));
+    DeviceCtx* c = new DeviceCtx;
+    c->device = device;
+    hipDeviceProp_t prop;
+    SIFT_HIP(hipGetDeviceProperties(&prop, device));
+    c->groups_max = std::max(1, std::min(prop.multiProcessorCount, kMaxGroups));
+    DeviceTables* h = new DeviceTables;
+    build_tables(h);
+    SIFT_HIP(hipMalloc(&c->d_tabs, sizeof(DeviceTables)));
+    SIFT_HIP(hipMemcpy(c->d_tabs, h, sizeof(DeviceTables), hipMemcpyHostToDevice));
+    delete h;
+    SIFT_HIP(hipMalloc(&c->d_ring, kRingSlots * kSlotWords * sizeof(uint32_t)));
+    SIFT_HIP(hipMalloc(&c->d_state, 256));
+    SIFT_HIP(hipSetDevice(prev));
+    g_ctx[device] = c;
+    *out = c;
+    return SIFT_OK;
+}
+
+// RAII device switch for calls that allocate or launch.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
+            ok = true;
+    }
+    ~DeviceGuard() {
+        if (ok && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// Geometry + launch of one compute(state, buf) over device memory.
+int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, const void* d_buf,
+                   uint64_t len, uint32_t xor_out, uint32_t* d_out, uint32_t* workspace,
+                   hipStream_t stream) {
+    if (!d_out) {
+        g_last_error = "d_out is NULL";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    if (len && !d_buf) {
+        g_last_error = "d_buf is NULL with len > 0";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    const uint64_t addr = reinterpret_cast<uint64_t>(d_buf);
+    const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
+    const int64_t nvec = (int64_t)(v1 - v0);
+
+    FinalArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.state_imm = state;
+    f.state_ptr = d_state_in;
+    f.xor_out = xor_out;
+    f.out = d_out;
+
+    if (nvec == 0) {
+        // Fewer than 16 bytes, all inside one vector: one lane walks them.
+        f.xpow_body = kOne;
+        f.tail = static_cast<const uint8_t*>(d_buf);
+        f.tail_len = (uint32_t)len;
+        f.groups = 0;
+        launch_combine(workspace, f, stream);
+        SIFT_HIP(hipGetLastError());
+        return SIFT_OK;
+    }
+
+    const uint32_t head_skip = (uint32_t)(addr & 15u);
+    const uint64_t body_bytes = (uint64_t)nvec * 16u - head_skip;
+    f.tail = reinterpret_cast<const uint8_t*>(v1 << 4);
+    f.tail_len = (uint32_t)((addr + len) & 15u);
+    f.xpow_body = gf2_xpow(x2n(), 8ull * body_bytes);
+
+    const int64_t ntile = (nvec + kTileVecs - 1) / kTileVecs;
+    int64_t groups = std::min<int64_t>(ntile, c->groups_max);
+    const int64_t tpg = (ntile + groups - 1) / groups;
+    groups = (ntile + tpg - 1) / tpg;
+    f.groups = (int32_t)groups;
+
+    uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
+    for (int s = 0; s < kTreeLevels; ++s) {
+        f.zpow[s] = z;
+        if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
+    }
+
+    TileArgs t;
+    t.vbase = reinterpret_cast<const u32x4*>(v0 << 4);
+    t.nvec = nvec;
+    t.tiles_per_group = tpg;
+    t.virtual_tiles = groups * tpg;
+    t.pad_tiles = groups * tpg - ntile;
+    t.tabs = c->d_tabs;
+    t.partial = workspace;
+    t.head_skip = head_skip;
+    t.fuse_final = groups == 1 ? 1u : 0u;
+
+    launch_tiles(t, f, (int)groups, tpg > 1, stream);
+    SIFT_HIP(hipGetLastError());
+    if (groups > 1) {
+        launch_combine(workspace, f, stream);
+        SIFT_HIP(hipGetLastError());
+    }
+    return SIFT_OK;
+}
+
+uint32_t* ring_slot(DeviceCtx* c) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    unsigned i = c->ring_next++ % kRingSlots;
+    return c->d_ring + (size_t)i * kSlotWords;
+}
+
+int ensure_staging(DeviceCtx* c) {
+    if (c->d_stage[0]) return SIFT_OK;
+    for (int i = 0; i < 2; ++i) {
+        SIFT_HIP(hipMalloc(&c->d_stage[i], kStagePiece));
+        SIFT_HIP(hipEventCreateWithFlags(&c->copied[i], hipEventDisableTiming));
+        SIFT_HIP(hipEventCreateWithFlags(&c->consumed[i], hipEventDisableTiming));
+    }
+    SIFT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    SIFT_HIP(hipStreamCreateWithFlags(&c->work_stream, hipStreamNonBlocking));
+    return SIFT_OK;
+}
+
+}  // namespace
+}  // namespace sift
+
+using namespace sift;
+
+extern "C" {
+
+const char* sift_strerror(int status) {
+    switch (status) {
+        case SIFT_OK: return "ok";
+        case SIFT_ERR_READ: return "Cannot read from file";                       // container.rs:8
+        case SIFT_ERR_WRITE: return "Cannot write to file";                       // container.rs:10
+        case SIFT_ERR_READ_INVALID_CHUNK_SIZE: return "Read a chunk with an invalid chunk size";  // :12
+        case SIFT_ERR_WRITE_INVALID_CHUNK_SIZE: return "Chunk size too large to be written";      // :14
+        case SIFT_ERR_READ_CRC_MISMATCH: return "CRC mismatch when reading data";                 // :16
+        case SIFT_ERR_NO_DEVICE: return "no usable HIP device";
+        case SIFT_ERR_HIP: return "HIP runtime error";
+        case SIFT_ERR_INVALID_ARG: return "invalid argument";
+        default: return "unknown status";
+    }
+}
+
+const char* sift_last_error(void) { return g_last_error.c_str(); }
+
+int sift_init(int device) {
+    DeviceCtx* c = nullptr;
+    return get_ctx(device, &c);
+}
+
+void sift_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (DeviceCtx* c : g_ctx) {
+        if (!c) continue;
+        DeviceGuard guard(c->device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(c->d_tabs);
+        (void)hipFree(c->d_ring);
+        (void)hipFree(c->d_state);
+        for (int i = 0; i < 2; ++i) {
+            if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+            if (c->copied[i]) (void)hipEventDestroy(c->copied[i]);
+            if (c->consumed[i]) (void)hipEventDestroy(c->consumed[i]);
+        }
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        if (c->work_stream) (void)hipStreamDestroy(c->work_stream);
+        delete c;
+    }
+    g_ctx.clear();
+}
+
+size_t sift_crc32_workspace_bytes(void) { return kSlotWords * sizeof(uint32_t); }
+
+int sift_crc32_compute_device(int device, uint32_t state, const uint32_t* d_state_in,
+                              const void* d_buf, uint64_t len, uint32_t* d_out, void* workspace,
+                              void* stream) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    uint32_t* ws = workspace ? static_cast<uint32_t*>(workspace) : ring_slot(c);
+    return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws,
+                          static_cast<hipStream_t>(stream));
+}
+
+int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf, uint64_t len,
+                                   uint32_t* out, void* stream) {
+    if (!out) {
+        g_last_error = "out is NULL";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    uint32_t* ws = ring_slot(c);
+    uint32_t* d_res = ws + kMaxGroups;  // result word lives in the slot's tail
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = launch_compute(c, state, nullptr, d_buf, len, 0u, d_res, ws, s);
+    if (rc != SIFT_OK) return rc;
+    SIFT_HIP(hipMemcpyAsync(out, d_res, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SIFT_HIP(hipStreamSynchronize(s));
+    return SIFT_OK;
+}
+
+int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_t len,
+                            uint32_t* out) {
+    if (!out || (len && !buf)) {
+        g_last_error = "NULL pointer";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(c->host_path_mutex);
+    rc = ensure_staging(c);
+    if (rc != SIFT_OK) return rc;
+
+    const uint8_t* src = static_cast<const uint8_t*>(buf);
+    uint32_t* ws = ring_slot(c);
+    // Running state lives in c->d_state between pieces; piece 0 starts from
+    // the immediate.  Empty input still runs one (empty) launch so that the
+    // result provably comes from the device path.
+    uint64_t off = 0;
+    int piece = 0;
+    do {
+        const uint64_t n = std::min<uint64_t>(kStagePiece, len - off);
+        const int b = piece & 1;
+        if (piece >= 2) SIFT_HIP(hipStreamWaitEvent(c->copy_stream, c->consumed[b], 0));
+        if (n)
+            SIFT_HIP(hipMemcpyAsync(c->d_stage[b], src + off, n, hipMemcpyHostToDevice,
+                                    c->copy_stream));
+        SIFT_HIP(hipEventRecord(c->copied[b], c->copy_stream));
+        SIFT_HIP(hipStreamWaitEvent(c->work_stream, c->copied[b], 0));
+        rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_stage[b], n, 0u,
+                            c->d_state, ws, c->work_stream);
+        if (rc != SIFT_OK) return rc;
+        SIFT_HIP(hipEventRecord(c->consumed[b], c->work_stream));
+        off += n;
+        ++piece;
+    } while (off < len);
+    SIFT_HIP(hipMemcpyAsync(out, c->d_state, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            c->work_stream));
+    SIFT_HIP(hipStreamSynchronize(c->work_stream));
+    return SIFT_OK;
+}
+
+void sift_digest_new(sift_digest* d, int device) {
+    d->value = SIFT_CRC_INIT;  // crc.rs:42
+    d->device = device;
+}
+
+int sift_digest_update(sift_digest* d, const void* buf, uint64_t len) {
+    uint32_t v = 0;
+    int rc = sift_crc32_compute_host(d->device, d->value, buf, len, &v);  // crc.rs:46
+    if (rc == SIFT_OK) d->value = v;
+    return rc;
+}
+
+int sift_digest_update_device(sift_digest* d, const void* d_buf, uint64_t len, void* stream) {
+    uint32_t v = 0;
+    int rc = sift_crc32_compute_device_sync(d->device, d->value, d_buf, len, &v, stream);
+    if (rc == SIFT_OK) d->value = v;
+    return rc;
+}
+
+uint32_t sift_digest_finalize(const sift_digest* d) { return d->value ^ 0xFFFFFFFFu; }  // crc.rs:51
+
+uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b) {
+    return gf2_mulmod(state_a, gf2_xpow(x2n(), 8ull * len_b)) ^ state_b0;
+}
+
+int sift_chunk_crc_device(int device, const void* d_type_and_data, uint64_t data_len,
+                          uint32_t* d_out, void* workspace, void* stream) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    uint32_t* ws = workspace ? static_cast<uint32_t*>(workspace) : ring_slot(c);
+    // container.rs:80-83: new() -> update(type) -> update(data) -> finalize().
+    // Two updates over adjacent bytes equal one update over their concatenation.
+    return launch_compute(c, SIFT_CRC_INIT, nullptr, d_type_and_data, data_len + 4u, 0xFFFFFFFFu,
+                          d_out, ws, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

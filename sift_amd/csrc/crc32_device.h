@@ -1,0 +1,64 @@
+// crc32_device.h -- structures shared by the kernels and the host API.
+//
+// Geometry.  One workgroup of kThreads lanes owns one CU (its LDS tables fill
+// most of the 160 KiB).  A "vector" is 16 bytes (one dwordx4 load per lane); a
+// "tile" is one vector per lane = kTileBytes contiguous bytes.  A workgroup
+// walks a contiguous run of tiles; lane t keeps four running words (one per
+// dword of its vector) and advances them with a Horner step whose stride is
+// one tile:
+//       acc <- acc * y + w,    y = x^(8 * kTileBytes) mod P
+// (the `* y` is four LDS table lookups, exactly as many as the reference's
+// byte table would need for the same four bytes, crc.rs:31).
+#pragma once
+
+#include <stdint.h>
+
+namespace sift {
+
+constexpr int kThreads = 1024;              // lanes per workgroup (16 waves)
+constexpr int kTileVecs = kThreads;         // 16-byte vectors per tile
+constexpr int kTileBytes = kThreads * 16;   // 16 KiB
+constexpr int kRepl = 32;                   // LDS copies of each table row (one per bank)
+constexpr int kMaxGroups = 1024;            // workgroups one call may launch
+constexpr int kTreeLevels = 10;             // log2(kMaxGroups)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Constant tables, built on the host once per device (crc32_api.hip).
+struct DeviceTables {
+    uint32_t Y[4 * 256];     // Y[k*256+b] = (b << 8k) * x^(8*kTileBytes) mod P
+    uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
+    uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
+};
+
+// Arguments of the tile kernel.
+struct TileArgs {
+    const u32x4* vbase;        // 16-byte aligned; vector 0 holds the first message byte
+    int64_t nvec;              // whole vectors in the body (vector 0 may be front-masked)
+    int64_t tiles_per_group;   // virtual tiles each workgroup owns
+    int64_t virtual_tiles;     // groups * tiles_per_group
+    int64_t pad_tiles;         // all-zero virtual tiles in front of the first real one
+    const DeviceTables* tabs;
+    uint32_t* partial;         // [groups] raw residues, one per workgroup
+    uint32_t head_skip;        // bytes of vector 0 that precede the message (zeroed)
+    uint32_t fuse_final;       // groups == 1: finish in this launch
+};
+
+// Arguments of the finishing step (combine kernel, or fused into the tile
+// kernel when one workgroup did all the work).
+struct FinalArgs {
+    uint32_t zpow[kTreeLevels];  // z^(2^s), z = x^(8 * tiles_per_group * kTileBytes)
+    uint32_t xpow_body;          // x^(8 * body_bytes): carries the incoming state across the body
+    uint32_t state_imm;          // incoming running state ...
+    const uint32_t* state_ptr;   // ... or, if non-null, where to read it on the device
+    const uint8_t* tail;         // bytes after the last whole vector (or the whole tiny input)
+    uint32_t tail_len;
+    uint32_t xor_out;            // 0, or 0xFFFFFFFF to finalize (Chunk::compute_crc)
+    uint32_t* out;
+    int32_t groups;
+};
+
+void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y, void* stream);
+void launch_combine(const uint32_t* partial, const FinalArgs& f, void* stream);
+
+}  // namespace sift

@@ -1,0 +1,140 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Mirrors the reference's own tests (sift-persist/src/crc.rs:66-131) and widens
+them to every size class and alignment the kernels distinguish.
+"""
+import ctypes as C
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+SEED = 0x51F7
+
+
+def _rand(n, seed=SEED):
+    return np.random.default_rng(seed).integers(0, 256, size=n, dtype=np.uint8)
+
+
+def test_reference_known_answers(gpu):
+    # crc.rs:71-96, :121-122, :127-128
+    with open(os.path.join(GOLDEN, "crc_kat.json")) as f:
+        kat = json.load(f)
+    for case in kat["reference_kat"]:
+        data = case["data"].encode()
+        want = int(case["crc"], 16)
+        assert gpu.crc32(data) == want, case
+        assert gpu.crc32(torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8)[: len(data)].cuda()) == want
+
+
+def test_test_check_format(gpu):
+    # crc.rs:119-123
+    assert "0x{:08x}".format(gpu.crc32(b"123456789")) == "0xcbf43926"
+
+
+def test_golden_random(gpu):
+    with open(os.path.join(GOLDEN, "crc_random.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        buf = _rand(case["len"], case["seed"])
+        t = torch.from_numpy(buf).cuda()
+        assert gpu.compute(int(case["state"], 16), t) == int(case["compute"], 16), case
+
+
+# Size classes: tiny (<16 B, one lane), one partial tile, one full tile
+# (16 KiB), several one-tile groups, first multi-tile case (y table), ragged
+# multi-tile, and sizes straddling every boundary by +-1.
+SIZES = sorted(set(
+    list(range(0, 70)) +
+    [127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097,
+     16383, 16384, 16385, 16400, 32767, 32768, 32769, 65536, 100000,
+     (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 3 * (1 << 20) + 12345,
+     256 * 16384 - 1, 256 * 16384, 256 * 16384 + 1, 257 * 16384 + 5,
+     512 * 16384, 512 * 16384 + 16, 5 * 256 * 16384 + 777, (64 << 20) + 3]))
+
+
+def test_sizes_vs_oracle(gpu, oracle):
+    big = _rand(max(SIZES) + 64)
+    dbig = torch.from_numpy(big).cuda()
+    for n in SIZES:
+        for state in (0xFFFFFFFF, 0, 0x12345678):
+            want = oracle.compute(state, big[:n])
+            got = gpu.compute(state, dbig[:n])
+            assert got == want, (n, hex(state), hex(got), hex(want))
+
+
+def test_alignments_vs_oracle(gpu, oracle):
+    big = _rand(3 * (1 << 20) + 256, seed=7)
+    dbig = torch.from_numpy(big).cuda()
+    for off in list(range(0, 33)) + [63, 64, 65, 255]:
+        for n in (0, 1, 5, 15, 16, 17, 31, 32, 33, 100, 16384, 16385, 70001, 2 * (1 << 20) + 3,
+                  3 * (1 << 20)):
+            want = oracle.compute(0xFFFFFFFF, big[off:off + n])
+            got = gpu.compute(0xFFFFFFFF, dbig[off:off + n])
+            assert got == want, (off, n, hex(got), hex(want))
+
+
+def test_host_buffer_path(gpu, oracle):
+    for n in (0, 1, 9, 4096, 100000, (32 << 20) - 1, (32 << 20), (32 << 20) + 1, (70 << 20) + 13):
+        buf = _rand(n, seed=n + 1)
+        assert gpu.compute(0xFFFFFFFF, buf) == oracle.compute(0xFFFFFFFF, buf), n
+        assert gpu.compute(0xFFFFFFFF, buf.tobytes()) == zlib.crc32(buf.tobytes()) ^ 0xFFFFFFFF
+
+
+def test_streaming_equals_one_shot(gpu, oracle):
+    # Digest::update chaining (crc.rs:45-47; container.rs:81-82 feeds type then data)
+    buf = _rand(1 << 20, seed=3)
+    d = gpu.Digest()
+    cuts = [0, 4, 4 + 1000, 4 + 1000 + 16384, 500000, 1 << 20]
+    for a, b in zip(cuts, cuts[1:]):
+        d.update(buf[a:b])
+    assert d.finalize() == oracle.crc32(buf)
+    d2 = gpu.Digest()
+    t = torch.from_numpy(buf).cuda()
+    for a, b in zip(cuts, cuts[1:]):
+        d2.update(t[a:b])
+    assert d2.finalize() == oracle.crc32(buf)
+
+
+def test_async_chain_on_stream(gpu, oracle):
+    buf = _rand((5 << 20) + 77, seed=11)
+    t = torch.from_numpy(buf).cuda()
+    state = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(gpu.workspace_bytes(), dtype=torch.uint8, device="cuda")
+    cuts = [0, 13, 1 << 20, (3 << 20) + 5, buf.size]
+    gpu.compute_async(0xFFFFFFFF, t[cuts[0]:cuts[1]], state, ws)
+    for a, b in zip(cuts[1:], cuts[2:]):
+        gpu.compute_async(state, t[a:b], state, ws)
+    torch.cuda.synchronize()
+    assert (int(state.item()) & 0xFFFFFFFF) == oracle.compute(0xFFFFFFFF, buf)
+
+
+def test_linearity_property(gpu):
+    # size-independent property at a large size: crc is affine over GF(2):
+    # compute(0, a^b) == compute(0, a) ^ compute(0, b)
+    n = (200 << 20) + 5
+    g = torch.Generator(device="cuda").manual_seed(SEED)
+    a = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    assert gpu.compute(0, a ^ b) == gpu.compute(0, a) ^ gpu.compute(0, b)
+
+
+def test_split_concat_property_full_size(gpu):
+    # BASELINE size (1 GiB, the container.rs:49 cap): whole == stitched halves
+    # at arbitrary cut points, and equals zlib on the host copy.
+    n = 1 << 30
+    g = torch.Generator(device="cuda").manual_seed(SEED)
+    t = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    whole = gpu.compute(0xFFFFFFFF, t)
+    for cut in (1, 12345, (1 << 29) + 7, n - 3):
+        sa = gpu.compute(0xFFFFFFFF, t[:cut])
+        sb = gpu.compute(0, t[cut:])
+        assert gpu.concat(sa, sb, n - cut) == whole, cut
+        assert gpu.compute(sa, t[cut:]) == whole, cut
+    assert whole ^ 0xFFFFFFFF == zlib.crc32(t.cpu().numpy().tobytes())
