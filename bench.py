@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- CRC-32 hot-path throughput on MI355X.
+
+BASELINE.json names no metric (it reads "N/A: exclude repo"); SURVEY.md section 8(d)
+defines the contingency workload measured here: compute(0xFFFFFFFF, buf)
+(sift-persist/src/crc.rs:28-34) over one 1 GiB buffer of uniform random bytes
+(seed 0x51F7), 1 GiB being the reference's chunk cap (container.rs:49).
+
+A step is one compute() over the whole buffer, resident in HBM before the
+timed region.  With N > 1 (one process per GPU) the logical buffer is N GiB,
+rank r owns range r, and a step additionally all-gathers one (state, length)
+pair per rank over RCCL and stitches them -- weak scaling, no data-path
+collective.
+
+Prints one JSON line (rank 0).  `roofline` is for the tile kernel, timed with
+HIP events on its own stream during the timed steps; `cpu_baseline` is the C
+port of the reference's byte-at-a-time loop (oracle/sift_oracle.c), 1 core, on
+a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x51F7
+GIB = 1 << 30
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(host_sample) -> dict:
+    """The oracle (C port of crc.rs:28-34) on one host core, bounded sample."""
+    from oracle import c_oracle
+    L = c_oracle.lib()
+    ptr = host_sample.ctypes.data
+    n = host_sample.size
+    t0 = time.perf_counter()
+    L.oracle_crc_repeat(ptr, n, 1)
+    one = time.perf_counter() - t0
+    passes = max(1, min(64, int(12.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    L.oracle_crc_repeat(ptr, n, passes)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n * passes / dt / 1e9, 4),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{passes} passes over the first {n >> 20} MiB of the workload buffer "
+                  f"({n * passes / GIB:.2f} GiB hashed, {dt:.1f} s)",
+    }
+
+
+def load_traffic(workload: str):
+    """HBM bytes per tile-kernel launch from the committed PMC run, or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("workload") == workload:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sift_amd
+    from sift_amd import _lib, sharded
+    _lib.check(_lib.lib.sift_init(local_rank))
+
+    n = args.bytes
+    g = torch.Generator(device=dev).manual_seed(SEED + rank)
+    buf = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g)
+    ws = torch.zeros(sift_amd.workspace_bytes(), dtype=torch.uint8, device=dev)
+    K, W = args.steps, args.warmup
+    pairs = torch.zeros(max(K, 1), 2, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(max(K, 1), 2 * world, dtype=torch.int64, device=dev)
+    pairs[:, 1] = n
+
+    def step(pair, gath):
+        sharded.local_state_async(0xFFFFFFFF, buf, rank, pair, ws)
+        if world > 1:
+            dist.all_gather_into_tensor(gath, pair)
+
+    def run(steps):
+        """`steps` passes of the hot path plus the read-back and host stitch of
+        every pass's result: the whole job, nothing cached between passes."""
+        for i in range(steps):
+            step(pairs[i], gathered[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            return [sharded.stitch([(s & 0xFFFFFFFF, l) for s, l in row.view(world, 2).tolist()])
+                    for row in gathered[:steps].cpu()]
+        return [int(s) & 0xFFFFFFFF for s in pairs[:steps, 0].cpu().tolist()]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    done = 0
+    while done < W:  # untimed: same code path, so lazy kernel loads happen here
+        c = min(W - done, max(K, 1))
+        run(c)
+        done += c
+    pairs[:, 0] = 0
+    fence()
+    _lib.check(_lib.lib.sift_profile_begin(local_rank, K))
+    t0 = time.perf_counter()
+    results = run(K)
+    fence()
+    dt = time.perf_counter() - t0
+    kms = C.c_double(0.0)
+    kl = C.c_int(0)
+    _lib.check(_lib.lib.sift_profile_end(local_rank, C.byref(kms), C.byref(kl)))
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert len(set(results)) == 1, "steps over the same buffer must agree"
+
+    if rank == 0:
+        total_bytes = float(n) * world * K
+        workload = f"compute(0xFFFFFFFF, {n >> 20} MiB uniform random bytes, seed 0x51F7) per GPU"
+        kernel_s = kms.value / 1e3 / max(kl.value, 1)
+        achieved = n / kernel_s / 1e9 if kl.value else None
+        out = {
+            "metric": "crc32_compute_throughput",
+            "value": round(total_bytes / dt / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (GF(2) polynomial arithmetic over u8 input)",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "note": "BASELINE.json metric is N/A; workload per SURVEY.md section 8(d): "
+                        "1 GiB = chunk cap of container.rs:49",
+                "bytes_per_gpu_per_step": n,
+                "result": f"0x{results[0]:08x}",
+                "parallelism": f"range-sharded x{world}, (state,len) all-gather" if world > 1
+                               else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "crc32_tiles_kernel<true>",
+                "achieved": round(achieved, 1) if achieved else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "kernel_us": round(kernel_s * 1e6, 2),
+                "launches_timed": kl.value,
+                "algorithmic_bytes_per_launch": n,
+                "traffic": load_traffic(workload),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = buf[: min(n, 256 << 20)].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,16 @@ void sift_shutdown(void);
  * needs when the caller brings its own (see `workspace` below). */
 size_t sift_crc32_workspace_bytes(void);
 
+/* ------------------------------------------------------------ measurement
+ * No reference counterpart.  Between _begin and _end every
+ * sift_crc32_compute_* / sift_chunk_crc_device launch on `device` brackets its
+ * tile kernel (the dominant kernel) with a HIP event pair on the launch's own
+ * stream, up to `max_launches` launches.  _end waits for them and returns the
+ * summed kernel time in milliseconds and the number of launches measured.
+ * bench.py divides algorithmic bytes by this for `roofline.achieved`. */
+int sift_profile_begin(int device, int max_launches);
+int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
+
 /* ------------------------------------------------------- crc.rs:28-34 ----
  * fn compute(crc: u32, buf: &[u8]) -> u32
  *

@@ -54,6 +54,11 @@ struct DeviceCtx {
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     std::mutex host_path_mutex;
+    // measurement support (sift_profile_begin / _end): event pairs around the
+    // tile kernel of each launch, recorded on the launch's own stream
+    std::vector<hipEvent_t> prof_events;
+    int prof_used = 0;
+    bool prof_on = false;
 };
 
 std::mutex g_ctx_mutex;
@@ -145,7 +150,6 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
 
     FinalArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.state_imm = state;
     f.state_ptr = d_state_in;
     f.xor_out = xor_out;
     f.out = d_out;
@@ -153,10 +157,13 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     if (nvec == 0) {
         // Fewer than 16 bytes, all inside one vector: one lane walks them.
         f.xpow_body = kOne;
+        f.state_term = state;
         f.tail = static_cast<const uint8_t*>(d_buf);
         f.tail_len = (uint32_t)len;
         f.groups = 0;
-        launch_combine(workspace, f, stream);
+        CombineMats none;
+        std::memset(&none, 0, sizeof(none));
+        launch_combine(workspace, f, none, stream);
         SIFT_HIP(hipGetLastError());
         return SIFT_OK;
     }
@@ -166,6 +173,7 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     f.tail = reinterpret_cast<const uint8_t*>(v1 << 4);
     f.tail_len = (uint32_t)((addr + len) & 15u);
     f.xpow_body = gf2_xpow(x2n(), 8ull * body_bytes);
+    f.state_term = d_state_in ? 0u : gf2_mulmod(state, f.xpow_body);
 
     const int64_t ntile = (nvec + kTileVecs - 1) / kTileVecs;
     int64_t groups = std::min<int64_t>(ntile, c->groups_max);
@@ -173,11 +181,6 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     groups = (ntile + tpg - 1) / tpg;
     f.groups = (int32_t)groups;
 
-    uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
-    for (int s = 0; s < kTreeLevels; ++s) {
-        f.zpow[s] = z;
-        if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
-    }
 
     TileArgs t;
     t.vbase = reinterpret_cast<const u32x4*>(v0 << 4);
@@ -190,10 +193,26 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     t.head_skip = head_skip;
     t.fuse_final = groups == 1 ? 1u : 0u;
 
+    const bool prof = c->prof_on && (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
+    if (prof) SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used], stream));
     launch_tiles(t, f, (int)groups, tpg > 1, stream);
     SIFT_HIP(hipGetLastError());
+    if (prof) {
+        SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used + 1], stream));
+        ++c->prof_used;
+    }
     if (groups > 1) {
-        launch_combine(workspace, f, stream);
+        CombineMats m;
+        uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
+        for (int s = 0; s < kTreeLevels; ++s) {
+            uint32_t r = z;
+            for (int k = 0; k < 32; ++k) {
+                m.z[s][k] = r;
+                r = gf2_mulx(r);
+            }
+            if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
+        }
+        launch_combine(workspace, f, m, stream);
         SIFT_HIP(hipGetLastError());
     }
     return SIFT_OK;
@@ -255,6 +274,7 @@ void sift_shutdown(void) {
         (void)hipFree(c->d_tabs);
         (void)hipFree(c->d_ring);
         (void)hipFree(c->d_state);
+        for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; ++i) {
             if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
             if (c->copied[i]) (void)hipEventDestroy(c->copied[i]);
@@ -265,6 +285,41 @@ void sift_shutdown(void) {
         delete c;
     }
     g_ctx.clear();
+}
+
+int sift_profile_begin(int device, int max_launches) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (max_launches < 0) max_launches = 0;
+    while ((int)c->prof_events.size() < 2 * max_launches) {
+        hipEvent_t e;
+        SIFT_HIP(hipEventCreate(&e));
+        c->prof_events.push_back(e);
+    }
+    c->prof_used = 0;
+    c->prof_on = true;
+    return SIFT_OK;
+}
+
+int sift_profile_end(int device, double* tile_kernel_ms, int* launches) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    c->prof_on = false;
+    double total = 0.0;
+    for (int i = 0; i < c->prof_used; ++i) {
+        SIFT_HIP(hipEventSynchronize(c->prof_events[2 * i + 1]));
+        float ms = 0.f;
+        SIFT_HIP(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+        total += ms;
+    }
+    if (tile_kernel_ms) *tile_kernel_ms = total;
+    if (launches) *launches = c->prof_used;
+    c->prof_used = 0;
+    return SIFT_OK;
 }
 
 size_t sift_crc32_workspace_bytes(void) { return kSlotWords * sizeof(uint32_t); }

@@ -47,10 +47,9 @@ struct TileArgs {
 // Arguments of the finishing step (combine kernel, or fused into the tile
 // kernel when one workgroup did all the work).
 struct FinalArgs {
-    uint32_t zpow[kTreeLevels];  // z^(2^s), z = x^(8 * tiles_per_group * kTileBytes)
     uint32_t xpow_body;          // x^(8 * body_bytes): carries the incoming state across the body
-    uint32_t state_imm;          // incoming running state ...
-    const uint32_t* state_ptr;   // ... or, if non-null, where to read it on the device
+    uint32_t state_term;         // state * x^(8 * body_bytes), when the state is an immediate ...
+    const uint32_t* state_ptr;   // ... or, if non-null, where to read the state on the device
     const uint8_t* tail;         // bytes after the last whole vector (or the whole tiny input)
     uint32_t tail_len;
     uint32_t xor_out;            // 0, or 0xFFFFFFFF to finalize (Chunk::compute_crc)
@@ -58,7 +57,13 @@ struct FinalArgs {
     int32_t groups;
 };
 
+// Row k of level s: z^(2^s) * x^k, z = x^(8 * tiles_per_group * kTileBytes).
+struct CombineMats {
+    uint32_t z[kTreeLevels][32];
+};
+
 void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y, void* stream);
-void launch_combine(const uint32_t* partial, const FinalArgs& f, void* stream);
+void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,
+                    void* stream);
 
 }  // namespace sift

@@ -28,6 +28,7 @@ namespace {
 constexpr int kYWords = 4 * 256 * kRepl;  // 32768 words = 128 KiB
 constexpr int kXWords = 4 * 256;          // 4 KiB, not replicated (used 16x per lane per launch)
 constexpr int kWaves = kThreads / 64;
+constexpr int kUnroll = 4;  // tiles in flight per lane, twice (current + next batch)
 
 // acc * y: four lookups in the bank-replicated table.  Entry (k, b) for bank
 // r lives at word ((k*256 + b) * 32 + r); lane l uses r = l & 31, so the 32
@@ -47,6 +48,12 @@ __device__ __forceinline__ uint32_t mul_x32(uint32_t v, const uint32_t* ldsX) {
 }
 
 __device__ __forceinline__ u32x4 load_vec(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// One lane's vector of a whole tile: buffer_load_dwordx4, non-temporal (the
+// stream is read once; aux bit 1 = nt).
+__device__ __forceinline__ u32x4 load_tile(__amdgpu_buffer_rsrc_t srd, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, /*aux*/ 2);
+}
 
 // Zero the first `skip` bytes (1..15) of a vector: they precede the message.
 __device__ __forceinline__ u32x4 mask_head(u32x4 w, uint32_t skip) {
@@ -68,8 +75,8 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t r) {
 
 // Incoming state and trailing bytes; one lane.
 __device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f) {
-    uint32_t s = f.state_ptr ? *f.state_ptr : f.state_imm;
-    uint32_t r = gf2_mulmod(s, f.xpow_body) ^ body;
+    // state * x^(8*body): folded on the host when the state is an immediate
+    uint32_t r = (f.state_ptr ? gf2_mulmod(*f.state_ptr, f.xpow_body) : f.state_term) ^ body;
     for (uint32_t i = 0; i < f.tail_len; ++i) r = crc_step_byte(r, f.tail[i]);
     *f.out = r ^ f.xor_out;
 }
@@ -98,14 +105,17 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     int64_t ntiles = tv1 - tv0;
 
     u32x4 acc = {0u, 0u, 0u, 0u};
-    const u32x4* p = nullptr;
+    // `p` is the tile's first vector: the same for every lane, so it and its
+    // increments live in scalar registers and each load is base + lane offset.
+    const u32x4* p = a.vbase;
     if (ntiles > 0) {
         // Tiles are aligned to the END of the body, so only the first real tile
         // can start before vector 0.
-        const int64_t vi = a.nvec - (a.virtual_tiles - tv0) * (int64_t)kTileVecs + (int64_t)tid;
-        p = a.vbase + vi;
+        const int64_t v0 = a.nvec - (a.virtual_tiles - tv0) * (int64_t)kTileVecs;
+        p = a.vbase + v0;
+        const int64_t vi = v0 + (int64_t)tid;
         if (vi >= 0) {
-            acc = load_vec(p);
+            acc = load_vec(p + tid);
             if (vi == 0 && a.head_skip) acc = mask_head(acc, a.head_skip);
         }
         p += kTileVecs;
@@ -123,18 +133,27 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     __syncthreads();
 
     if (USE_Y) {
-        constexpr int U = 4;
+        // The rest of the run through a buffer descriptor: 128-bit SRD in
+        // scalar registers, per-lane offset tid*16 in one VGPR, tile offset in
+        // an SGPR -- no 64-bit vector address arithmetic in the loop.  Every
+        // tile from here on is whole, so the range check never fires.
+        const uint32_t run_bytes = (uint32_t)ntiles * (uint32_t)kTileBytes;
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u32x4*>(p), /*stride*/ 0, (int)run_bytes, 0x00020000);
+        const int voff = (int)(tid * 16u);
+        int soff = 0;
+        constexpr int U = kUnroll;
         if (ntiles >= U) {
             u32x4 cur[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = load_vec(p + u * kTileVecs);
-            p += U * kTileVecs;
+            for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
+            soff += U * kTileBytes;
             ntiles -= U;
             while (ntiles >= U) {
                 u32x4 nxt[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) nxt[u] = load_vec(p + u * kTileVecs);
-                p += U * kTileVecs;
+                for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
+                soff += U * kTileBytes;
                 ntiles -= U;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -151,8 +170,8 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
             }
         }
         while (ntiles > 0) {
-            u32x4 w = load_vec(p);
-            p += kTileVecs;
+            u32x4 w = load_tile(srd, voff, soff);
+            soff += kTileBytes;
             --ntiles;
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
@@ -180,24 +199,39 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 }
 
 // Tree over the workgroup residues.  Residue of group g carries weight
-// z^(G-1-g); index h = G-1-g so the weights are z^h and level s multiplies the
-// upper half of each pair by z^(2^s).
+// z^(G-1-g); with h = G-1-g the weights are z^h, and level s folds element
+// h + 2^s into element h (h a multiple of 2^(s+1)) after multiplying it by
+// z^(2^s).  Each such product is done by 32 lanes together: lane k holds row k
+// of the constant's matrix, zmat[s][k] = z^(2^s) * x^k (built on the host), and
+// contributes it when bit 31-k of the operand is set; a 5-step XOR butterfly
+// inside the half-wave sums the rows.  ~15 instructions per level instead of a
+// 32-step serial multiply per lane.
 __global__ __launch_bounds__(kMaxGroups) void crc32_combine_kernel(const uint32_t* partial,
-                                                                   FinalArgs f) {
+                                                                   FinalArgs f, CombineMats m) {
     __shared__ uint32_t sh[kMaxGroups];
-    const int h = threadIdx.x;
+    const int tid = threadIdx.x;
     const int G = f.groups;
-    uint32_t v = (h < G) ? partial[G - 1 - h] : 0u;
-    sh[h] = v;
+    if (tid < G) sh[tid] = partial[G - 1 - tid];
+    const int k = tid & 31;
+    const int hw = tid >> 5;
+    constexpr int kHalfWaves = kMaxGroups / 32;
     for (int s = 0; (1 << s) < G; ++s) {
         __syncthreads();
-        const bool active = ((h & ((2 << s) - 1)) == 0) && (h + (1 << s) < G);
-        if (active) {
-            v ^= gf2_mulmod(sh[h + (1 << s)], f.zpow[s]);
-            sh[h] = v;
+        const uint32_t row = m.z[s][k];
+        const int stride = 2 << s;
+        const int nprod = (G - (1 << s) + stride - 1) / stride;
+        for (int j0 = 0; j0 < nprod; j0 += kHalfWaves) {
+            const int j = j0 + hw;
+            const bool valid = j < nprod;
+            const uint32_t a = valid ? sh[j * stride + (1 << s)] : 0u;
+            uint32_t t = ((a >> (31 - k)) & 1u) ? row : 0u;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
+            if (valid && k == 0) sh[j * stride] ^= t;
         }
     }
-    if (h == 0) finish(v, f);
+    __syncthreads();
+    if (tid == 0) finish(G > 0 ? sh[0] : 0u, f);
 }
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y, void* stream) {
@@ -208,11 +242,12 @@ void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y,
         hipLaunchKernelGGL(crc32_tiles_kernel<false>, dim3(groups), dim3(kThreads), 0, s, t, f);
 }
 
-void launch_combine(const uint32_t* partial, const FinalArgs& f, void* stream) {
+void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,
+                    void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int block = 64;
-    while (block < f.groups) block <<= 1;
-    hipLaunchKernelGGL(crc32_combine_kernel, dim3(1), dim3(block), 0, s, partial, f);
+    // Tiny inputs (no residues) need one lane only; otherwise all 32 half-waves.
+    const int block = f.groups > 0 ? kMaxGroups : 64;
+    hipLaunchKernelGGL(crc32_combine_kernel, dim3(1), dim3(block), 0, s, partial, f, m);
 }
 
 }  // namespace sift
