@@ -61,7 +61,9 @@ int sift_init(int device);
 /* Frees everything sift_init allocated on every device. */
 void sift_shutdown(void);
 /* Bytes of device workspace one in-flight sift_crc32_compute_device call
- * needs when the caller brings its own (see `workspace` below). */
+ * needs when the caller brings its own (see `workspace` below).  A caller's
+ * workspace must be zero-filled once before its first use; the library leaves
+ * it reusable (its arrival counter back at zero) after every call. */
 size_t sift_crc32_workspace_bytes(void);
 
 /* ------------------------------------------------------------ measurement
@@ -73,6 +75,14 @@ size_t sift_crc32_workspace_bytes(void);
  * bench.py divides algorithmic bytes by this for `roofline.achieved`. */
 int sift_profile_begin(int device, int max_launches);
 int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
+
+/* Measurement knobs, process-wide.  No reference counterpart. */
+enum {
+    SIFT_TUNE_SINGLE_LAUNCH = 1 /* 1 (default): the last workgroup to arrive combines the
+                                   residues inside the tile kernel; 0: a second, combine
+                                   kernel does (A/B measurement only, same results) */
+};
+int sift_tune(int key, int value);
 
 /* ------------------------------------------------------- crc.rs:28-34 ----
  * fn compute(crc: u32, buf: &[u8]) -> u32

@@ -23,6 +23,8 @@ ERR_NO_DEVICE = 16
 ERR_HIP = 17
 ERR_INVALID_ARG = 18
 
+TUNE_SINGLE_LAUNCH = 1
+
 HEADER_LEN = 9
 CHUNK_SIZE_LIMIT = 1024 * 1024 * 1024
 CRC_INIT = 0xFFFFFFFF
@@ -30,7 +32,7 @@ CRC_INIT = 0xFFFFFFFF
 # every symbol include/sift_amd.h declares; tests check the .so exports them all
 EXPORTS = (
     "sift_strerror", "sift_last_error", "sift_init", "sift_shutdown",
-    "sift_profile_begin", "sift_profile_end", "sift_crc32_workspace_bytes", "sift_crc32_compute_device",
+    "sift_profile_begin", "sift_profile_end", "sift_tune", "sift_crc32_workspace_bytes", "sift_crc32_compute_device",
     "sift_crc32_compute_device_sync", "sift_crc32_compute_host",
     "sift_digest_new", "sift_digest_update", "sift_digest_update_device",
     "sift_digest_finalize", "sift_crc32_concat", "sift_chunk_crc_device",
@@ -69,6 +71,8 @@ def _load() -> C.CDLL:
     L.sift_profile_begin.argtypes = [i32, i32]
     L.sift_profile_end.restype = i32
     L.sift_profile_end.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32)]
+    L.sift_tune.restype = i32
+    L.sift_tune.argtypes = [i32, i32]
     L.sift_crc32_workspace_bytes.restype = C.c_size_t
     L.sift_crc32_workspace_bytes.argtypes = []
     L.sift_crc32_compute_device.restype = i32

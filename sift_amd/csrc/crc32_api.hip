@@ -22,6 +22,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Finish inside the tile kernel (last group to arrive combines) instead of a
+// second launch.  sift_tune(SIFT_TUNE_SINGLE_LAUNCH, 0) selects the two-launch
+// form for A/B measurement.
+bool g_single_launch = true;
+
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return SIFT_ERR_HIP;
@@ -34,7 +39,9 @@ int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kRingSlots = 64;
-constexpr size_t kSlotWords = kMaxGroups + 16;   // residues + one result word (+pad)
+constexpr size_t kSlotWords = kMaxGroups + 64;   // residues | result word | ... | counter (own line)
+constexpr size_t kResultWord = kMaxGroups;       // sync API's result
+constexpr size_t kCounterWord = kMaxGroups + 32; // arrival counter, zero between calls
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
 
 const X2nTable& x2n() {
@@ -112,6 +119,7 @@ int get_ctx(int device, DeviceCtx** out) {
     SIFT_HIP(hipMemcpy(c->d_tabs, h, sizeof(DeviceTables), hipMemcpyHostToDevice));
     delete h;
     SIFT_HIP(hipMalloc(&c->d_ring, kRingSlots * kSlotWords * sizeof(uint32_t)));
+    SIFT_HIP(hipMemset(c->d_ring, 0, kRingSlots * kSlotWords * sizeof(uint32_t)));
     SIFT_HIP(hipMalloc(&c->d_state, 256));
     SIFT_HIP(hipSetDevice(prev));
     g_ctx[device] = c;
@@ -190,19 +198,13 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     t.pad_tiles = groups * tpg - ntile;
     t.tabs = c->d_tabs;
     t.partial = workspace;
+    t.counter = workspace + kCounterWord;
     t.head_skip = head_skip;
     t.fuse_final = groups == 1 ? 1u : 0u;
+    t.single_launch = (groups > 1 && g_single_launch) ? 1u : 0u;
 
-    const bool prof = c->prof_on && (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
-    if (prof) SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used], stream));
-    launch_tiles(t, f, (int)groups, tpg > 1, stream);
-    SIFT_HIP(hipGetLastError());
-    if (prof) {
-        SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used + 1], stream));
-        ++c->prof_used;
-    }
+    CombineMats m;
     if (groups > 1) {
-        CombineMats m;
         uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
         for (int s = 0; s < kTreeLevels; ++s) {
             uint32_t r = z;
@@ -212,6 +214,19 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
             }
             if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
         }
+    } else {
+        std::memset(&m, 0, sizeof(m));
+    }
+
+    const bool prof = c->prof_on && (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
+    if (prof) SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used], stream));
+    launch_tiles(t, f, m, (int)groups, tpg > 1, stream);
+    SIFT_HIP(hipGetLastError());
+    if (prof) {
+        SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used + 1], stream));
+        ++c->prof_used;
+    }
+    if (groups > 1 && !t.single_launch) {
         launch_combine(workspace, f, m, stream);
         SIFT_HIP(hipGetLastError());
     }
@@ -322,6 +337,17 @@ int sift_profile_end(int device, double* tile_kernel_ms, int* launches) {
     return SIFT_OK;
 }
 
+int sift_tune(int key, int value) {
+    switch (key) {
+        case SIFT_TUNE_SINGLE_LAUNCH:
+            g_single_launch = value != 0;
+            return SIFT_OK;
+        default:
+            g_last_error = "unknown tuning key";
+            return SIFT_ERR_INVALID_ARG;
+    }
+}
+
 size_t sift_crc32_workspace_bytes(void) { return kSlotWords * sizeof(uint32_t); }
 
 int sift_crc32_compute_device(int device, uint32_t state, const uint32_t* d_state_in,
@@ -355,7 +381,7 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf
         return SIFT_ERR_HIP;
     }
     uint32_t* ws = ring_slot(c);
-    uint32_t* d_res = ws + kMaxGroups;  // result word lives in the slot's tail
+    uint32_t* d_res = ws + kResultWord;
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = launch_compute(c, state, nullptr, d_buf, len, 0u, d_res, ws, s);
     if (rc != SIFT_OK) return rc;

@@ -39,9 +39,11 @@ struct TileArgs {
     int64_t virtual_tiles;     // groups * tiles_per_group
     int64_t pad_tiles;         // all-zero virtual tiles in front of the first real one
     const DeviceTables* tabs;
-    uint32_t* partial;         // [groups] raw residues, one per workgroup
+    uint32_t* partial;         // [groups] residues, one per workgroup
+    uint32_t* counter;         // arrival counter for the single-launch finish; zero between calls
     uint32_t head_skip;        // bytes of vector 0 that precede the message (zeroed)
-    uint32_t fuse_final;       // groups == 1: finish in this launch
+    uint32_t fuse_final;       // groups == 1: finish in this launch, no exchange
+    uint32_t single_launch;    // groups > 1: last group to arrive combines and finishes
 };
 
 // Arguments of the finishing step (combine kernel, or fused into the tile
@@ -62,7 +64,8 @@ struct CombineMats {
     uint32_t z[kTreeLevels][32];
 };
 
-void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y, void* stream);
+void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
+                  bool use_y, void* stream);
 void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,
                     void* stream);
 

@@ -84,7 +84,8 @@ __device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f) {
 }  // namespace
 
 template <bool USE_Y>
-__global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, FinalArgs f) {
+__global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, FinalArgs f,
+                                                               CombineMats m) {
     // One array (see the guide's second-__shared__-object trap); the one-tile
     // variant needs no y table and so leaves the CU's LDS to other workgroups.
     constexpr int kYUsed = USE_Y ? kYWords : 0;
@@ -120,6 +121,15 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         }
         p += kTileVecs;
         --ntiles;
+    }
+
+    // Single-launch finish (a.single_launch): wave 0 will weight this group's
+    // residue by z^(G-1-g) at the end; fetch its matrix rows now, behind the
+    // first data load.
+    uint32_t rows[kTreeLevels];
+    if (a.single_launch && tid < 64u) {
+#pragma unroll
+        for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][lane32];
     }
 
     // Tables: global (L2-resident, 8 KiB) -> LDS, issued behind the first load.
@@ -187,14 +197,60 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     r = wave_xor(r);
     if ((tid & 63u) == 0) red[tid >> 6] = r;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t x = 0;
+    if (tid >= 64u) return;
+
+    // Wave 0 finishes the group.
+    uint32_t x = wave_xor(tid < (uint32_t)kWaves ? red[tid] : 0u);
+    if (a.fuse_final) {  // one group did everything
+        if (tid == 0) finish(x, f);
+        return;
+    }
+    if (!a.single_launch) {  // two-launch form: raw residue, combine kernel weights it
+        if (tid == 0) a.partial[g] = x;
+        return;
+    }
+
+    // Weight: x * z^h, h = G-1-g, as a product of the z^(2^s) with bit s of h
+    // set; each factor applied by the half-wave together (lane k holds row k).
+    const uint32_t G = (uint32_t)f.groups;
+    const uint32_t h = G - 1u - (uint32_t)g;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) x ^= red[w];
-        if (a.fuse_final)
-            finish(x, f);
-        else
-            a.partial[g] = x;
+    for (int s = 0; s < kTreeLevels; ++s) {
+        if ((h >> s) & 1u) {  // uniform
+            uint32_t t = ((x >> (31u - lane32)) & 1u) ? rows[s] : 0u;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
+            x = t;
+        }
+    }
+
+    // Publish and take a ticket (guide: Guideline 16, counter form).  The
+    // residue goes out as an agent-scope atomic store (write-through), is
+    // drained, released at agent scope, drained again, and only then does the
+    // same lane add to the counter.
+    uint32_t ticket = 0;
+    if (tid == 0) {
+        __hip_atomic_store(&a.partial[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket != G - 1u) return;
+
+    // Last group to arrive: every residue is published.  Acquire at agent
+    // scope, then read them with agent-scope atomic loads, XOR, finish, and
+    // leave the counter at zero for the next call on this workspace.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t v = 0;
+    for (uint32_t i = tid; i < G; i += 64u)
+        v ^= __hip_atomic_load(&a.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = wave_xor(v);
+    if (tid == 0) {
+        __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finish(v, f);
     }
 }
 
@@ -215,9 +271,15 @@ __global__ __launch_bounds__(kMaxGroups) void crc32_combine_kernel(const uint32_
     const int k = tid & 31;
     const int hw = tid >> 5;
     constexpr int kHalfWaves = kMaxGroups / 32;
-    for (int s = 0; (1 << s) < G; ++s) {
+    // All ten rows up front: one memory latency instead of one per level.
+    uint32_t rows[kTreeLevels];
+#pragma unroll
+    for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][k];
+#pragma unroll
+    for (int s = 0; s < kTreeLevels; ++s) {
+        if ((1 << s) >= G) break;
         __syncthreads();
-        const uint32_t row = m.z[s][k];
+        const uint32_t row = rows[s];
         const int stride = 2 << s;
         const int nprod = (G - (1 << s) + stride - 1) / stride;
         for (int j0 = 0; j0 < nprod; j0 += kHalfWaves) {
@@ -234,12 +296,13 @@ __global__ __launch_bounds__(kMaxGroups) void crc32_combine_kernel(const uint32_
     if (tid == 0) finish(G > 0 ? sh[0] : 0u, f);
 }
 
-void launch_tiles(const TileArgs& t, const FinalArgs& f, int groups, bool use_y, void* stream) {
+void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
+                  bool use_y, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (use_y)
-        hipLaunchKernelGGL(crc32_tiles_kernel<true>, dim3(groups), dim3(kThreads), 0, s, t, f);
+        hipLaunchKernelGGL(crc32_tiles_kernel<true>, dim3(groups), dim3(kThreads), 0, s, t, f, m);
     else
-        hipLaunchKernelGGL(crc32_tiles_kernel<false>, dim3(groups), dim3(kThreads), 0, s, t, f);
+        hipLaunchKernelGGL(crc32_tiles_kernel<false>, dim3(groups), dim3(kThreads), 0, s, t, f, m);
 }
 
 void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,

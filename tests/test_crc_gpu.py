@@ -138,3 +138,37 @@ def test_split_concat_property_full_size(gpu):
         assert gpu.concat(sa, sb, n - cut) == whole, cut
         assert gpu.compute(sa, t[cut:]) == whole, cut
     assert whole ^ 0xFFFFFFFF == zlib.crc32(t.cpu().numpy().tobytes())
+
+
+def test_two_launch_form_matches(gpu, oracle):
+    # The A/B measurement path (separate combine kernel) must give the same bits.
+    from sift_amd import _lib
+    big = _rand((40 << 20) + 99, seed=5)
+    d = torch.from_numpy(big).cuda()
+    try:
+        _lib.check(_lib.lib.sift_tune(_lib.TUNE_SINGLE_LAUNCH, 0))
+        for n in (16385, 300000, (8 << 20) + 1, big.size):
+            assert gpu.compute(0xFFFFFFFF, d[3:3 + n - 3]) == oracle.compute(0xFFFFFFFF, big[3:n]), n
+    finally:
+        _lib.check(_lib.lib.sift_tune(_lib.TUNE_SINGLE_LAUNCH, 1))
+
+
+def test_back_to_back_calls_share_workspace(gpu, oracle):
+    # Single-launch finish: residues and the arrival counter live in one
+    # workspace reused by consecutive calls on a stream.  Different buffers
+    # and sizes back to back, no host sync in between, every result checked
+    # (a stale residue or a counter left non-zero would show here).
+    rng = np.random.default_rng(99)
+    bufs = [rng.integers(0, 256, size=int(n), dtype=np.uint8)
+            for n in rng.integers(20000, 6 << 20, size=24)]
+    dbufs = [torch.from_numpy(b).cuda() for b in bufs]
+    ws = torch.zeros(gpu.workspace_bytes(), dtype=torch.uint8, device="cuda")
+    outs = torch.zeros(len(bufs) * 5, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for i, d in enumerate(dbufs):
+            gpu.compute_async(0xFFFFFFFF, d, outs[rep * len(bufs) + i: rep * len(bufs) + i + 1], ws)
+    torch.cuda.synchronize()
+    got = [int(v) & 0xFFFFFFFF for v in outs.cpu().tolist()]
+    want = [oracle.compute(0xFFFFFFFF, b) for b in bufs]
+    assert got == want * 5

@@ -1,0 +1,162 @@
+// hbm_read_probe.hip -- measurement tool (not part of the product).
+// Times pure-read kernels over the bench workload (1 GiB) next to the
+// library's tile kernel, interleaved in one process, to place the practical
+// HBM read ceiling on the same device the CRC kernel runs on.
+//   build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_probe tools/hbm_read_probe.hip \
+//          -Lsift_amd -lsift_amd -Wl,-rpath,'$ORIGIN/../sift_amd'
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../include/sift_amd.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));            \
+            std::exit(1);                                                          \
+        }                                                                          \
+    } while (0)
+
+__global__ void fill(uint32_t* p, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        p[i] = x;
+    }
+}
+
+// Same geometry as crc32_tiles_kernel: one 1024-lane workgroup per CU walks a
+// contiguous run of 16 KiB tiles, U loads in flight per lane; XOR only.
+template <int U, bool NT>
+__global__ __launch_bounds__(1024) void read_runs(const u32x4* base, size_t tiles_per_group,
+                                                  uint32_t* out) {
+    const u32x4* p = base + (size_t)blockIdx.x * tiles_per_group * 1024 + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    size_t t = 0;
+    for (; t + U <= tiles_per_group; t += U) {
+        u32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = NT ? __builtin_nontemporal_load(p + (t + u) * 1024) : p[(t + u) * 1024];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= w[u];
+    }
+    for (; t < tiles_per_group; ++t) acc ^= p[t * 1024];
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;  // keeps the loads alive
+}
+
+// Conventional streaming read: 256-lane workgroups, grid-stride.
+template <bool NT>
+__global__ __launch_bounds__(256) void read_gridstride(const u32x4* base, size_t nvec, uint32_t* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        u32x4 a = NT ? __builtin_nontemporal_load(base + i) : base[i];
+        u32x4 b = NT ? __builtin_nontemporal_load(base + i + stride) : base[i + stride];
+        u32x4 c = NT ? __builtin_nontemporal_load(base + i + 2 * stride) : base[i + 2 * stride];
+        u32x4 d = NT ? __builtin_nontemporal_load(base + i + 3 * stride) : base[i + 3 * stride];
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < nvec; i += stride) acc ^= base[i];
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;
+}
+
+int main(int argc, char** argv) {
+    const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 0) : (size_t)1 << 30;
+    const int rounds = argc > 2 ? std::atoi(argv[2]) : 30;
+    CK(hipSetDevice(0));
+    uint8_t* buf;
+    uint32_t* out;
+    CK(hipMalloc(&buf, n));
+    CK(hipMalloc(&out, 1 << 16));
+    fill<<<4096, 256>>>((uint32_t*)buf, n / 4);
+    CK(hipDeviceSynchronize());
+    if (sift_init(0) != SIFT_OK) {
+        std::fprintf(stderr, "sift_init: %s\n", sift_last_error());
+        return 1;
+    }
+    const size_t nvec = n / 16, tiles = nvec / 1024, tpg = tiles / 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const char* names[] = {"read_runs<4,nt>  (crc geometry)", "read_runs<8,nt>", "read_runs<4,plain>",
+                           "gridstride 256x2048 nt", "gridstride 256x4096 plain",
+                           "sift tile kernel (events)", "sift compute, whole call"};
+    const int nv = 7;
+    std::vector<std::vector<float>> ms(nv);
+    for (int r = 0; r < rounds + 3; ++r) {
+        for (int v = 0; v < nv; ++v) {
+            float t = 0;
+            if (v == 5) {
+                sift_profile_begin(0, 1);
+                sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, n, out, nullptr, nullptr);
+                double kms = 0;
+                int k = 0;
+                sift_profile_end(0, &kms, &k);
+                t = (float)kms;
+            } else {
+                CK(hipEventRecord(e0));
+                switch (v) {
+                    case 0: read_runs<4, true><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 1: read_runs<8, true><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 2: read_runs<4, false><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 3: read_gridstride<true><<<2048, 256>>>((const u32x4*)buf, nvec, out); break;
+                    case 4: read_gridstride<false><<<4096, 256>>>((const u32x4*)buf, nvec, out); break;
+                    case 6:
+                        sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, n, out, nullptr, nullptr);
+                        break;
+                }
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&t, e0, e1));
+            }
+            if (r >= 3) ms[v].push_back(t);
+        }
+    }
+    std::printf("bytes %zu, rounds %d (interleaved)\n", n, rounds);
+    for (int v = 0; v < nv; ++v) {
+        std::sort(ms[v].begin(), ms[v].end());
+        float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
+        std::printf("%-34s median %8.2f us (%7.1f GB/s)   min %8.2f us (%7.1f GB/s)\n", names[v],
+                    med * 1e3, n / (med * 1e-3) / 1e9, mn * 1e3, n / (mn * 1e-3) / 1e9);
+    }
+    // Back-to-back launches on one stream, no host sync in between: what a
+    // sustained run (bench.py) sees per launch, gaps included.
+    const int reps = 50;
+    for (int v = 0; v < 2; ++v) {
+        std::vector<float> per;
+        for (int r = 0; r < 5; ++r) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) {
+                if (v == 0)
+                    read_runs<4, true><<<256, 1024>>>((const u32x4*)buf, tpg, out);
+                else
+                    sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, n, out, nullptr, nullptr);
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float t = 0;
+            CK(hipEventElapsedTime(&t, e0, e1));
+            per.push_back(t / reps);
+        }
+        std::sort(per.begin(), per.end());
+        std::printf("back-to-back x%d %-22s median %8.2f us/launch (%7.1f GB/s)  min %8.2f\n", reps,
+                    v == 0 ? "read_runs<4,nt>" : "sift compute", per[2] * 1e3,
+                    n / (per[2] * 1e-3) / 1e9, per[0] * 1e3);
+    }
+    return 0;
+}
