@@ -73,10 +73,12 @@ def load_traffic(workload: str):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--bytes", type=int, default=GIB, help="bytes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="bracket every n-th launch's tile kernel with HIP events")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +137,7 @@ def main() -> None:
         done += c
     pairs[:, 0] = 0
     fence()
-    _lib.check(_lib.lib.sift_profile_begin(local_rank, K))
+    _lib.check(_lib.lib.sift_profile_begin(local_rank, K, args.event_stride))
     t0 = time.perf_counter()
     results = run(K)
     fence()

@@ -67,13 +67,15 @@ void sift_shutdown(void);
 size_t sift_crc32_workspace_bytes(void);
 
 /* ------------------------------------------------------------ measurement
- * No reference counterpart.  Between _begin and _end every
+ * No reference counterpart.  Between _begin and _end every `stride`-th
  * sift_crc32_compute_* / sift_chunk_crc_device launch on `device` brackets its
  * tile kernel (the dominant kernel) with a HIP event pair on the launch's own
- * stream, up to `max_launches` launches.  _end waits for them and returns the
- * summed kernel time in milliseconds and the number of launches measured.
+ * stream, up to `max_launches` bracketed launches.  (An event pair costs a few
+ * microseconds of idle GPU around the kernel, hence the stride.)  _end waits
+ * for them and returns the summed kernel time in milliseconds and the number
+ * of launches measured.
  * bench.py divides algorithmic bytes by this for `roofline.achieved`. */
-int sift_profile_begin(int device, int max_launches);
+int sift_profile_begin(int device, int max_launches, int stride);
 int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
 
 /* Measurement knobs, process-wide.  No reference counterpart. */

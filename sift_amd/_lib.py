@@ -68,7 +68,7 @@ def _load() -> C.CDLL:
     L.sift_shutdown.restype = None
     L.sift_shutdown.argtypes = []
     L.sift_profile_begin.restype = i32
-    L.sift_profile_begin.argtypes = [i32, i32]
+    L.sift_profile_begin.argtypes = [i32, i32, i32]
     L.sift_profile_end.restype = i32
     L.sift_profile_end.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32)]
     L.sift_tune.restype = i32

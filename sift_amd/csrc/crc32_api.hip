@@ -16,7 +16,6 @@
 
 namespace sift {
 
-static_assert(kThreads == 1024, "table fill in crc32_tiles_kernel assumes 1024 lanes");
 
 namespace {
 
@@ -39,9 +38,11 @@ int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kRingSlots = 64;
-constexpr size_t kSlotWords = kMaxGroups + 64;   // residues | result word | ... | counter (own line)
-constexpr size_t kResultWord = kMaxGroups;       // sync API's result
-constexpr size_t kCounterWord = kMaxGroups + 32; // arrival counter, zero between calls
+// Workspace slot, in u32 words: residues (two-launch form) | result word |
+// u64 XOR accumulator (own 128-B line) | u64 arrival counter (own line).
+constexpr size_t kResultWord = kMaxGroups;         // sync API's result
+constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32 words on
+constexpr size_t kSlotWords = kMaxGroups + 96;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
 
 const X2nTable& x2n() {
@@ -65,6 +66,7 @@ struct DeviceCtx {
     // tile kernel of each launch, recorded on the launch's own stream
     std::vector<hipEvent_t> prof_events;
     int prof_used = 0;
+    int prof_stride = 1, prof_seen = 0;
     bool prof_on = false;
 };
 
@@ -112,7 +114,7 @@ int get_ctx(int device, DeviceCtx** out) {
     c->device = device;
     hipDeviceProp_t prop;
     SIFT_HIP(hipGetDeviceProperties(&prop, device));
-    c->groups_max = std::max(1, std::min(prop.multiProcessorCount, kMaxGroups));
+    c->groups_max = std::max(1, std::min(prop.multiProcessorCount * kGroupsPerCu, kMaxGroups));
     DeviceTables* h = new DeviceTables;
     build_tables(h);
     SIFT_HIP(hipMalloc(&c->d_tabs, sizeof(DeviceTables)));
@@ -198,7 +200,7 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     t.pad_tiles = groups * tpg - ntile;
     t.tabs = c->d_tabs;
     t.partial = workspace;
-    t.counter = workspace + kCounterWord;
+    t.exchange = workspace + kExchangeWord;
     t.head_skip = head_skip;
     t.fuse_final = groups == 1 ? 1u : 0u;
     t.single_launch = (groups > 1 && g_single_launch) ? 1u : 0u;
@@ -218,7 +220,8 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
         std::memset(&m, 0, sizeof(m));
     }
 
-    const bool prof = c->prof_on && (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
+    const bool prof = c->prof_on && (c->prof_seen++ % c->prof_stride) == 0 &&
+                      (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
     if (prof) SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used], stream));
     launch_tiles(t, f, m, (int)groups, tpg > 1, stream);
     SIFT_HIP(hipGetLastError());
@@ -302,7 +305,7 @@ void sift_shutdown(void) {
     g_ctx.clear();
 }
 
-int sift_profile_begin(int device, int max_launches) {
+int sift_profile_begin(int device, int max_launches, int stride) {
     DeviceCtx* c = nullptr;
     int rc = get_ctx(device, &c);
     if (rc != SIFT_OK) return rc;
@@ -314,6 +317,8 @@ int sift_profile_begin(int device, int max_launches) {
         c->prof_events.push_back(e);
     }
     c->prof_used = 0;
+    c->prof_seen = 0;
+    c->prof_stride = stride > 0 ? stride : 1;
     c->prof_on = true;
     return SIFT_OK;
 }

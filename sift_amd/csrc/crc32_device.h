@@ -15,10 +15,30 @@
 
 namespace sift {
 
-constexpr int kThreads = 1024;              // lanes per workgroup (16 waves)
+// Tunable at build time (-DSIFT_THREADS=..., tools/hbm_read_probe.hip builds
+// variants to compare); the shipped values are the measured best.
+#ifndef SIFT_THREADS
+#define SIFT_THREADS 1024
+#endif
+#ifndef SIFT_REPL
+#define SIFT_REPL 32
+#endif
+#ifndef SIFT_UNROLL
+#define SIFT_UNROLL 2
+#endif
+#ifndef SIFT_GROUPS_PER_CU
+#define SIFT_GROUPS_PER_CU 1
+#endif
+
+constexpr int kThreads = SIFT_THREADS;      // lanes per workgroup
 constexpr int kTileVecs = kThreads;         // 16-byte vectors per tile
-constexpr int kTileBytes = kThreads * 16;   // 16 KiB
-constexpr int kRepl = 32;                   // LDS copies of each table row (one per bank)
+constexpr int kTileBytes = kThreads * 16;   // 16 KiB at 1024 lanes
+constexpr int kRepl = SIFT_REPL;            // LDS copies of each table row (32 = one per bank)
+constexpr int kReplLog2 = kRepl == 32 ? 5 : kRepl == 16 ? 4 : kRepl == 8 ? 3 : -1;
+constexpr int kUnroll = SIFT_UNROLL;        // tiles in flight per lane, twice (current + next batch)
+constexpr int kGroupsPerCu = SIFT_GROUPS_PER_CU;  // resident workgroups per CU the LDS budget allows
+static_assert(kReplLog2 > 0, "SIFT_REPL must be 8, 16 or 32");
+static_assert(kThreads % 64 == 0 && kThreads >= 64 && kThreads <= 1024, "SIFT_THREADS");
 constexpr int kMaxGroups = 1024;            // workgroups one call may launch
 constexpr int kTreeLevels = 10;             // log2(kMaxGroups)
 
@@ -40,7 +60,8 @@ struct TileArgs {
     int64_t pad_tiles;         // all-zero virtual tiles in front of the first real one
     const DeviceTables* tabs;
     uint32_t* partial;         // [groups] residues, one per workgroup
-    uint32_t* counter;         // arrival counter for the single-launch finish; zero between calls
+    uint32_t* exchange;        // single-launch finish: u64 XOR accumulator, and 128 B on a u64
+                               // arrival counter; both zero between calls
     uint32_t head_skip;        // bytes of vector 0 that precede the message (zeroed)
     uint32_t fuse_final;       // groups == 1: finish in this launch, no exchange
     uint32_t single_launch;    // groups > 1: last group to arrive combines and finishes

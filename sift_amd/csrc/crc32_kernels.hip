@@ -21,6 +21,10 @@
 #include "crc32_device.h"
 #include "gf2.h"
 
+#ifndef SIFT_LOAD_AUX
+#define SIFT_LOAD_AUX 2  // nt
+#endif
+
 namespace sift {
 
 namespace {
@@ -28,17 +32,17 @@ namespace {
 constexpr int kYWords = 4 * 256 * kRepl;  // 32768 words = 128 KiB
 constexpr int kXWords = 4 * 256;          // 4 KiB, not replicated (used 16x per lane per launch)
 constexpr int kWaves = kThreads / 64;
-constexpr int kUnroll = 4;  // tiles in flight per lane, twice (current + next batch)
 
 // acc * y: four lookups in the bank-replicated table.  Entry (k, b) for bank
 // r lives at word ((k*256 + b) * 32 + r); lane l uses r = l & 31, so the 32
 // lanes of a ds_read_b32 lane group hit 32 different banks whatever b is.
 __device__ __forceinline__ uint32_t mul_y(uint32_t a, const uint32_t* ldsY, uint32_t lane32) {
-    uint32_t i0 = ((a & 0xffu) << 5) + lane32;
-    uint32_t i1 = (((a >> 8) & 0xffu) << 5) + lane32;
-    uint32_t i2 = (((a >> 16) & 0xffu) << 5) + lane32;
-    uint32_t i3 = ((a >> 24) << 5) + lane32;
-    return ldsY[i0] ^ ldsY[8192 + i1] ^ ldsY[16384 + i2] ^ ldsY[24576 + i3];
+    constexpr int T = 256 * kRepl;  // words per table
+    uint32_t i0 = ((a & 0xffu) << kReplLog2) + lane32;
+    uint32_t i1 = (((a >> 8) & 0xffu) << kReplLog2) + lane32;
+    uint32_t i2 = (((a >> 16) & 0xffu) << kReplLog2) + lane32;
+    uint32_t i3 = ((a >> 24) << kReplLog2) + lane32;
+    return ldsY[i0] ^ ldsY[T + i1] ^ ldsY[2 * T + i2] ^ ldsY[3 * T + i3];
 }
 
 // v * x^32: the reference's table step applied to four bytes at once.
@@ -52,7 +56,7 @@ __device__ __forceinline__ u32x4 load_vec(const u32x4* p) { return __builtin_non
 // One lane's vector of a whole tile: buffer_load_dwordx4, non-temporal (the
 // stream is read once; aux bit 1 = nt).
 __device__ __forceinline__ u32x4 load_tile(__amdgpu_buffer_rsrc_t srd, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, /*aux*/ 2);
+    return __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, /*aux*/ SIFT_LOAD_AUX);
 }
 
 // Zero the first `skip` bytes (1..15) of a vector: they precede the message.
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     uint32_t* red = ldsX + kXWords;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane32 = tid & 31u;
+    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);  // which table copy this lane reads
+    const uint32_t row32 = tid & 31u;                     // its row in a 32-lane product
     const int64_t g = blockIdx.x;
 
     // This workgroup's virtual tiles [tv0, tv1); the ones before pad_tiles are
@@ -129,36 +134,42 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     uint32_t rows[kTreeLevels];
     if (a.single_launch && tid < 64u) {
 #pragma unroll
-        for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][lane32];
+        for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][row32];
     }
 
-    // Tables: global (L2-resident, 8 KiB) -> LDS, issued behind the first load.
-    if (USE_Y) {
-#pragma unroll 4
-        for (int i = 0; i < kYWords / kThreads; ++i)
-            ldsY[i * kThreads + tid] = a.tabs->Y[i * (kThreads / kRepl) + (tid >> 5)];
+    // The rest of the run goes through a buffer descriptor: 128-bit SRD in
+    // scalar registers, per-lane offset tid*16 in one VGPR, tile offset in an
+    // SGPR -- no 64-bit vector address arithmetic in the loop.  Every tile from
+    // here on is whole, so the range check never fires.
+    const uint32_t run_bytes = (uint32_t)(ntiles > 0 ? ntiles : 0) * (uint32_t)kTileBytes;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(p), /*stride*/ 0, (int)run_bytes, 0x00020000);
+    const int voff = (int)(tid * 16u);
+    int soff = 0;
+    constexpr int U = kUnroll;
+    // First batch of the main loop is issued BEFORE the tables are staged, so
+    // HBM latency and the table fill overlap.
+    u32x4 cur[U];
+    const bool batched = USE_Y && ntiles >= U;
+    if (batched) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
+        soff += U * kTileBytes;
+        ntiles -= U;
     }
-    ldsX[tid] = a.tabs->X[tid];
+
+    // Tables: global (L2-resident, 8 KiB) -> LDS.
+    if (USE_Y) {
+#pragma unroll 16
+        for (int i = 0; i < kYWords / kThreads; ++i)
+            ldsY[i * kThreads + tid] = a.tabs->Y[i * (kThreads / kRepl) + (tid >> kReplLog2)];
+    }
+    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = a.tabs->X[i];
     const uint32_t kt = a.tabs->Kt[tid];
     __syncthreads();
 
     if (USE_Y) {
-        // The rest of the run through a buffer descriptor: 128-bit SRD in
-        // scalar registers, per-lane offset tid*16 in one VGPR, tile offset in
-        // an SGPR -- no 64-bit vector address arithmetic in the loop.  Every
-        // tile from here on is whole, so the range check never fires.
-        const uint32_t run_bytes = (uint32_t)ntiles * (uint32_t)kTileBytes;
-        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<u32x4*>(p), /*stride*/ 0, (int)run_bytes, 0x00020000);
-        const int voff = (int)(tid * 16u);
-        int soff = 0;
-        constexpr int U = kUnroll;
-        if (ntiles >= U) {
-            u32x4 cur[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
-            soff += U * kTileBytes;
-            ntiles -= U;
+        if (batched) {
             while (ntiles >= U) {
                 u32x4 nxt[U];
 #pragma unroll
@@ -217,40 +228,38 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int s = 0; s < kTreeLevels; ++s) {
         if ((h >> s) & 1u) {  // uniform
-            uint32_t t = ((x >> (31u - lane32)) & 1u) ? rows[s] : 0u;
+            uint32_t t = ((x >> (31u - row32)) & 1u) ? rows[s] : 0u;
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
             x = t;
         }
     }
 
-    // Publish and take a ticket (guide: Guideline 16, counter form).  The
-    // residue goes out as an agent-scope atomic store (write-through), is
-    // drained, released at agent scope, drained again, and only then does the
-    // same lane add to the counter.
-    uint32_t ticket = 0;
+    // Exchange through two 8-byte agent-scope read-modify-write atomics, both
+    // sides (guide: Guideline 16 / microarch "Valid forms": atomics execute at
+    // the memory side, so neither L1 nor a per-XCD L2 can serve a stale copy
+    // and no cache write-back or invalidate is needed).  One lane XORs the
+    // weighted residue into the accumulator, WAITS for that atomic to return,
+    // and only then adds to the arrival counter.  The group whose add returns
+    // G-1 knows every other group's XOR has been performed; it swaps the
+    // accumulator out (leaving zero for the next call), zeroes the counter
+    // and finishes.
     if (tid == 0) {
-        __hip_atomic_store(&a.partial[g], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ticket = __shfl(ticket, 0, 64);
-    if (ticket != G - 1u) return;
-
-    // Last group to arrive: every residue is published.  Acquire at agent
-    // scope, then read them with agent-scope atomic loads, XOR, finish, and
-    // leave the counter at zero for the next call on this workspace.
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t v = 0;
-    for (uint32_t i = tid; i < G; i += 64u)
-        v ^= __hip_atomic_load(&a.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v = wave_xor(v);
-    if (tid == 0) {
-        __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        finish(v, f);
+        unsigned long long* accp = reinterpret_cast<unsigned long long*>(a.exchange);
+        unsigned long long* cntp = accp + 16;  // its own 128-byte line
+        // Returning form + explicit wait: the XOR has been performed at the
+        // memory side before the add can issue.
+        unsigned long long old =
+            __hip_atomic_fetch_xor(accp, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+        unsigned long long ticket =
+            __hip_atomic_fetch_add(cntp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (unsigned long long)(G - 1u)) {
+            unsigned long long v =
+                __hip_atomic_exchange(accp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_exchange(cntp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            finish((uint32_t)v, f);
+        }
     }
 }
 

@@ -9,7 +9,7 @@ out = torch.zeros(2, dtype=torch.int32, device='cuda')
 for prof in (False, True):
     for _ in range(5): sift_amd.compute_async(0xFFFFFFFF, buf, out, ws)
     torch.cuda.synchronize()
-    if prof: _lib.lib.sift_profile_begin(0, 100)
+    if prof: _lib.lib.sift_profile_begin(0, 100, 1)
     t0=time.perf_counter()
     for _ in range(50): sift_amd.compute_async(0xFFFFFFFF, buf, out, ws)
     t1=time.perf_counter()

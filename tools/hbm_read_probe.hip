@@ -2,8 +2,7 @@
 // Times pure-read kernels over the bench workload (1 GiB) next to the
 // library's tile kernel, interleaved in one process, to place the practical
 // HBM read ceiling on the same device the CRC kernel runs on.
-//   build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_read_probe tools/hbm_read_probe.hip \
-//          -Lsift_amd -lsift_amd -Wl,-rpath,'$ORIGIN/../sift_amd'
+//   build: make -C tools   (compiles the library sources in, so -DSIFT_* variants can be compared)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -75,6 +74,26 @@ __global__ __launch_bounds__(256) void read_gridstride(const u32x4* base, size_t
     if (r == 0x12345678u) out[blockIdx.x] = r;
 }
 
+__global__ __launch_bounds__(1024) void empty_kernel(uint32_t* out) {
+    if (threadIdx.x == 5000) out[0] = 1;
+}
+
+// One load per lane + LDS reduce + one atomic per group: the irreducible part
+// of a one-tile-per-group call.
+__global__ __launch_bounds__(1024) void one_tile_atomic(const u32x4* base, unsigned long long* acc) {
+    __shared__ uint32_t red[16];
+    u32x4 w = __builtin_nontemporal_load(base + (size_t)blockIdx.x * 1024 + threadIdx.x);
+    uint32_t r = w.x ^ w.y ^ w.z ^ w.w;
+    for (int off = 32; off >= 1; off >>= 1) r ^= __shfl_xor(r, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t x = 0;
+        for (int i = 0; i < 16; ++i) x ^= red[i];
+        __hip_atomic_fetch_xor(acc, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 0) : (size_t)1 << 30;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 30;
@@ -102,7 +121,7 @@ int main(int argc, char** argv) {
         for (int v = 0; v < nv; ++v) {
             float t = 0;
             if (v == 5) {
-                sift_profile_begin(0, 1);
+                sift_profile_begin(0, 1, 1);
                 sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, n, out, nullptr, nullptr);
                 double kms = 0;
                 int k = 0;
@@ -133,6 +152,47 @@ int main(int argc, char** argv) {
         float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
         std::printf("%-34s median %8.2f us (%7.1f GB/s)   min %8.2f us (%7.1f GB/s)\n", names[v],
                     med * 1e3, n / (med * 1e-3) / 1e9, mn * 1e3, n / (mn * 1e-3) / 1e9);
+    }
+    {
+        std::vector<float> t0, t1;
+        for (int r = 0; r < 20; ++r) {
+            float t;
+            CK(hipEventRecord(e0));
+            empty_kernel<<<256, 1024>>>(out);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&t, e0, e1));
+            t0.push_back(t);
+            CK(hipEventRecord(e0));
+            one_tile_atomic<<<256, 1024>>>((const u32x4*)buf, (unsigned long long*)(out + 64));
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&t, e0, e1));
+            t1.push_back(t);
+        }
+        std::sort(t0.begin(), t0.end());
+        std::sort(t1.begin(), t1.end());
+        std::printf("floor: empty 256x1024 kernel median %6.2f us; one load + reduce + atomic per group %6.2f us\n",
+                    t0[10] * 1e3, t1[10] * 1e3);
+    }
+    // Fixed cost of a call: same grid, 2 tiles per group (table fill + tail +
+    // exchange, almost no streaming), and 1 tile per group (no y table).
+    {
+        const size_t small[2] = {(size_t)256 * 2 * 16384, (size_t)256 * 16384};
+        for (int v = 0; v < 2; ++v) {
+            std::vector<float> t;
+            for (int r = 0; r < 20; ++r) {
+                sift_profile_begin(0, 1, 1);
+                sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, small[v], out, nullptr, nullptr);
+                double kms = 0;
+                int k = 0;
+                sift_profile_end(0, &kms, &k);
+                t.push_back((float)kms);
+            }
+            std::sort(t.begin(), t.end());
+            std::printf("fixed cost: %zu KiB (%s) kernel median %6.2f us  min %6.2f us\n", small[v] >> 10,
+                        v == 0 ? "2 tiles/group, y table" : "1 tile/group", t[10] * 1e3, t[0] * 1e3);
+        }
     }
     // Back-to-back launches on one stream, no host sync in between: what a
     // sustained run (bench.py) sees per launch, gaps included.
