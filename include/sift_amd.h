@@ -142,6 +142,31 @@ uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b);
 int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data_len,
                           uint32_t *d_out, void *workspace, void *stream);
 
+/* ------------------------------------------------ many buffers at once -----
+ * The data-parallel form of the two functions above, for callers that hold
+ * many independent buffers / serialized chunks in HBM (bulk load of many
+ * files).  One wave per buffer; buffers over 1 MiB in crc mode take the
+ * whole-chip path one by one.  `offsets` / `lens` are HOST arrays of n
+ * entries (byte offset from `d_base`, byte length); results go to device
+ * memory, asynchronously on `stream`.
+ *
+ * sift_crc32_batch_device:  d_out[i] = compute(state, buffer i) ^ xor_out
+ *                           (crc.rs:28-34 applied n times; state = 0xFFFFFFFF,
+ *                           xor_out = 0xFFFFFFFF gives Digest new/update/finalize).
+ * sift_read_chunks_device:  Chunk::read (container.rs:47-66) on n serialized
+ *                           chunks; avail[i] = bytes readable from offsets[i].
+ *                           d_status[i] = SIFT_OK, SIFT_ERR_READ,
+ *                           SIFT_ERR_READ_INVALID_CHUNK_SIZE or
+ *                           SIFT_ERR_READ_CRC_MISMATCH, raised in the reference's
+ *                           order; d_data_len[i] (optional, may be NULL) = data
+ *                           length of chunk i if it parsed, else 0. */
+int sift_crc32_batch_device(int device, uint32_t state, uint32_t xor_out, const void *d_base,
+                            const uint64_t *offsets, const uint64_t *lens, uint32_t n,
+                            uint32_t *d_out, void *stream);
+int sift_read_chunks_device(int device, const void *d_base, const uint64_t *offsets,
+                            const uint64_t *avail, uint32_t n, uint32_t *d_status,
+                            uint32_t *d_data_len, void *stream);
+
 /* ------------------------------------------- container.rs:104-126 --------
  * write_header / read_header on byte slices.  Return bytes written/consumed
  * (9) or -SIFT_ERR_*. */

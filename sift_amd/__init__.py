@@ -6,5 +6,5 @@ Python mirror of the reference's interface used by the tests and bench.
 Importing it requires the built library -- there is no CPU fallback.
 """
 from . import _lib  # noqa: F401  (raises ImportError if the .so is missing)
-from .crc import Digest, compute, compute_async, concat, crc32, workspace_bytes  # noqa: F401
+from .crc import Digest, compute, compute_async, compute_batch, concat, crc32, workspace_bytes  # noqa: F401
 from . import container  # noqa: F401

@@ -99,3 +99,23 @@ def crc32(buf) -> int:
 def concat(state_a: int, state_b0: int, len_b: int) -> int:
     """compute(s, A|B) from compute(s, A), compute(0, B) and len(B)."""
     return int(lib.sift_crc32_concat(state_a & 0xFFFFFFFF, state_b0 & 0xFFFFFFFF, len_b))
+
+
+def compute_batch(crc: int, base: torch.Tensor, offsets, lens, xor_out: int = 0,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """compute(crc, buffer i) ^ xor_out for n buffers inside the device tensor
+    `base` (crc.rs:28-34 applied n times, one wave per buffer).  `offsets` and
+    `lens` are host sequences.  Returns an int32 device tensor (bit pattern of
+    the u32 results); asynchronous on the current stream."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    assert off.shape == ln.shape and off.ndim == 1
+    if off.size and int((off + ln).max()) > base.numel():
+        raise ValueError("a buffer reaches past the end of base")
+    dev = base.device.index
+    if out is None:
+        out = torch.empty(off.size, dtype=torch.int32, device=base.device)
+    check(lib.sift_crc32_batch_device(dev, crc & 0xFFFFFFFF, xor_out & 0xFFFFFFFF, base.data_ptr(),
+                                      off.ctypes.data, ln.ctypes.data, off.size, out.data_ptr(),
+                                      _stream_ptr(dev)))
+    return out

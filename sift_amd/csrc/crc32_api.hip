@@ -81,6 +81,9 @@ void build_tables(DeviceTables* t) {
             t->Y[k * 256 + b] = gf2_mulmod(b << (8 * k), y);
             t->X[k * 256 + b] = gf2_mulmod(b << (8 * k), x32);
         }
+    const uint32_t y1 = gf2_xpow(x2n(), 8ull * 1024);
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t b = 0; b < 256; ++b) t->Y1[k * 256 + b] = gf2_mulmod(b << (8 * k), y1);
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {
@@ -465,6 +468,82 @@ uint32_t sift_digest_finalize(const sift_digest* d) { return d->value ^ 0xFFFFFF
 
 uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b) {
     return gf2_mulmod(state_a, gf2_xpow(x2n(), 8ull * len_b)) ^ state_b0;
+}
+
+namespace {
+
+// Buffers longer than this leave the one-wave-per-buffer kernel and take the
+// whole-chip path one by one.
+constexpr uint64_t kBatchWaveMax = 1ull << 20;
+
+int run_batch(int device, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
+              uint32_t n, uint32_t state, uint32_t xor_out, bool verify, uint32_t* d_out,
+              uint32_t* d_data_len, hipStream_t stream) {
+    if (n == 0) return SIFT_OK;
+    if (!offsets || !lens || !d_out || !d_base) {
+        g_last_error = "NULL pointer";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    std::vector<BatchItem> items(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        items[i].offset = offsets[i];
+        // crc mode: long buffers are skipped by the wave kernel (len 0 -> trivial) and redone below
+        items[i].len = (!verify && lens[i] > kBatchWaveMax) ? 0 : lens[i];
+    }
+    BatchItem* d_items = nullptr;
+    SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_items), sizeof(BatchItem) * n, stream));
+    // pageable source: the runtime stages it before returning, so `items` may die with this frame
+    SIFT_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, stream));
+    BatchArgs b;
+    b.base = static_cast<const uint8_t*>(d_base);
+    b.items = d_items;
+    b.n = n;
+    b.state = state;
+    b.xor_out = xor_out;
+    b.verify = verify ? 1u : 0u;
+    b.chunk_limit = SIFT_CHUNK_SIZE_LIMIT;
+    b.out = d_out;
+    b.data_len = d_data_len;
+    b.tabs = c->d_tabs;
+    const int waves_per_group = kThreads / 64;
+    int groups = (int)std::min<uint64_t>((n + waves_per_group - 1) / waves_per_group,
+                                         (uint64_t)c->groups_max);
+    launch_batch(b, groups, stream);
+    SIFT_HIP(hipGetLastError());
+    SIFT_HIP(hipFreeAsync(d_items, stream));
+    if (!verify) {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (lens[i] <= kBatchWaveMax) continue;
+            rc = launch_compute(c, state, nullptr, static_cast<const uint8_t*>(d_base) + offsets[i],
+                                lens[i], xor_out, d_out + i, ring_slot(c), stream);
+            if (rc != SIFT_OK) return rc;
+        }
+    }
+    return SIFT_OK;
+}
+
+}  // namespace
+
+int sift_crc32_batch_device(int device, uint32_t state, uint32_t xor_out, const void* d_base,
+                            const uint64_t* offsets, const uint64_t* lens, uint32_t n,
+                            uint32_t* d_out, void* stream) {
+    return run_batch(device, d_base, offsets, lens, n, state, xor_out, false, d_out, nullptr,
+                     static_cast<hipStream_t>(stream));
+}
+
+int sift_read_chunks_device(int device, const void* d_base, const uint64_t* offsets,
+                            const uint64_t* avail, uint32_t n, uint32_t* d_status,
+                            uint32_t* d_data_len, void* stream) {
+    return run_batch(device, d_base, offsets, avail, n, 0, 0, true, d_status, d_data_len,
+                     static_cast<hipStream_t>(stream));
 }
 
 int sift_chunk_crc_device(int device, const void* d_type_and_data, uint64_t data_len,

@@ -49,6 +49,7 @@ struct DeviceTables {
     uint32_t Y[4 * 256];     // Y[k*256+b] = (b << 8k) * x^(8*kTileBytes) mod P
     uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
+    uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
 };
 
 // Arguments of the tile kernel.
@@ -84,6 +85,31 @@ struct FinalArgs {
 struct CombineMats {
     uint32_t z[kTreeLevels][32];
 };
+
+// Batch kernel (one wave per buffer).  kBatchItem describes one buffer:
+// `offset` bytes from `base`; `len` bytes long.  In verify mode the item is a
+// serialized chunk (container.rs:47-66): `len` is the number of bytes
+// available from `offset`, the chunk's own length comes from its header.
+struct BatchItem {
+    uint64_t offset;
+    uint64_t len;
+};
+
+struct BatchArgs {
+    const uint8_t* base;
+    const BatchItem* items;
+    uint32_t n;
+    uint32_t state;       // starting register for every buffer (crc mode)
+    uint32_t xor_out;     // crc mode: XORed into each result
+    uint32_t verify;      // 0: out[i] = compute(state, buffer i) ^ xor_out
+                          // 1: out[i] = status of Chunk::read on item i (SIFT_OK / SIFT_ERR_*)
+    uint32_t chunk_limit; // verify: container.rs:49 size cap
+    uint32_t* out;
+    uint32_t* data_len;   // verify, optional: data length of each chunk that parsed
+    const DeviceTables* tabs;
+};
+
+void launch_batch(const BatchArgs& b, int groups, void* stream);
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);

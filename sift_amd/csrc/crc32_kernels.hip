@@ -305,6 +305,160 @@ __global__ __launch_bounds__(kMaxGroups) void crc32_combine_kernel(const uint32_
     if (tid == 0) finish(G > 0 ? sh[0] : 0u, f);
 }
 
+
+// ---------------------------------------------------------------------------
+// Batch kernel: many independent buffers, ONE WAVE PER BUFFER.  This is the
+// data-parallel shape of the reference's load path when many files / chunks
+// are checked at once (Chunk::read x n, container.rs:47-66).  Same algebra as
+// the tile kernel at wave scale: a tile is 64 lanes x 16 B = 1 KiB, the Horner
+// step multiplies by y1 = x^(8*1024).  The starting register is folded into
+// the first four message bytes (valid for len >= 4: byte k of the state has
+// the same weight x^(8(len-k)) as message byte k), so no x^(8 len) is needed.
+// Buffers shorter than 32 bytes are walked by one lane.
+namespace {
+
+// XOR the bytes of the starting register that belong to vector `vi` into it:
+// message byte k (k = 0..3) sits h + k bytes into vector 0.
+__device__ __forceinline__ u32x4 fold_state(u32x4 w, int64_t vi, uint32_t h, uint32_t state) {
+    if (vi > 1) return w;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t pos = h + k;
+        if ((int64_t)(pos >> 4) == vi) {
+            const uint32_t word = (pos & 15u) >> 2;
+            const uint32_t bits = ((state >> (8u * k)) & 0xffu) << (8u * (pos & 3u));
+            w[0] ^= word == 0 ? bits : 0u;
+            w[1] ^= word == 1 ? bits : 0u;
+            w[2] ^= word == 2 ? bits : 0u;
+            w[3] ^= word == 3 ? bits : 0u;
+        }
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
+                                             const uint32_t* ldsY, const uint32_t* ldsX,
+                                             uint32_t lane, uint32_t lane32, uint32_t aw) {
+    if (len < 32u) {
+        uint32_t r = state;
+        if (lane == 0)
+            for (uint32_t i = 0; i < (uint32_t)len; ++i) r = crc_step_byte(r, ptr[i]);
+        return __shfl(r, 0, 64);
+    }
+    const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
+    const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
+    const int64_t nvec = (int64_t)(v1 - v0);  // >= 1, body >= 17 bytes
+    const uint32_t h = (uint32_t)(addr & 15u);
+    const u32x4* vbase = reinterpret_cast<const u32x4*>(v0 << 4);
+    const int64_t ntile = (nvec + 63) >> 6;
+    int64_t vi = nvec - ntile * 64 + (int64_t)lane;  // tiles aligned to the end of the body
+
+    // Tile 0 may start before vector 0 (front padding, head mask).  The four
+    // state bytes land in vectors 0 and 1, which are in tile 0 or, when tile 0
+    // holds vector 0 alone, in tiles 0 and 1: both are peeled.
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    if (vi >= 0) {
+        acc = vbase[vi];
+        if (vi == 0 && h) acc = mask_head(acc, h);
+        acc = fold_state(acc, vi, h, state);
+    }
+    vi += 64;
+    int64_t left = ntile - 1;
+    const u32x4* p = vbase + vi;
+    if (left > 0) {
+        u32x4 w = fold_state(*p, vi, h, state);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
+        p += 64;
+        --left;
+    }
+    for (; left >= 2; left -= 2) {
+        u32x4 w0 = __builtin_nontemporal_load(p);
+        u32x4 w1 = __builtin_nontemporal_load(p + 64);
+        p += 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w0[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w1[c];
+    }
+    if (left > 0) {
+        u32x4 w = __builtin_nontemporal_load(p);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+    r = gf2_mulmod(r, aw);
+    r = wave_xor(r);
+    // trailing bytes after the last whole vector
+    const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
+    if (tail_len) {
+        const uint8_t* tail = reinterpret_cast<const uint8_t*>(v1 << 4);
+        if (lane == 0)
+            for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, tail[i]);
+        r = __shfl(r, 0, 64);
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
+    __shared__ uint32_t lds[kYWords + kXWords];
+    uint32_t* ldsY = lds;
+    uint32_t* ldsX = lds + kYWords;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
+#pragma unroll 16
+    for (int i = 0; i < kYWords / kThreads; ++i)
+        ldsY[i * kThreads + tid] = b.tabs->Y1[i * (kThreads / kRepl) + (tid >> kReplLog2)];
+    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
+    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
+    __syncthreads();
+
+    const uint32_t wave = blockIdx.x * (uint32_t)kWaves + (tid >> 6);
+    const uint32_t nwaves = gridDim.x * (uint32_t)kWaves;
+    for (uint32_t i = wave; i < b.n; i += nwaves) {
+        const BatchItem it = b.items[i];
+        const uint8_t* ptr = b.base + it.offset;
+        if (!b.verify) {
+            const uint32_t r = wave_crc(ptr, it.len, b.state, ldsY, ldsX, lane, lane32, aw);
+            if (lane == 0) b.out[i] = r ^ b.xor_out;
+            continue;
+        }
+        // Chunk::read (container.rs:47-66) on the serialized chunk at ptr, it.len bytes available.
+        uint32_t status = 0, dlen = 0;
+        if (it.len < 4) {
+            status = 1;  // Error::Read
+        } else {
+            dlen = be32(ptr);
+            if (dlen > b.chunk_limit) status = 3;                  // ReadInvalidChunkSize, :49-52
+            else if (it.len < 12ull + (uint64_t)dlen) status = 1;  // read_exact fails, :54-60
+        }
+        if (status == 0) {
+            // container.rs:79-84: digest over type | data = ptr[4 .. 8+dlen), finalized
+            const uint32_t crc =
+                wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
+            if (crc != be32(ptr + 8 + dlen)) status = 5;           // ReadCrcMismatch, :60-63
+        }
+        if (lane == 0) {
+            b.out[i] = status;
+            if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
+        }
+    }
+}
+
+void launch_batch(const BatchArgs& b, int groups, void* stream) {
+    hipLaunchKernelGGL(crc32_batch_kernel, dim3(groups), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), b);
+}
+
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);

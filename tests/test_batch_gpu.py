@@ -1,0 +1,87 @@
+"""GPU parity for the many-buffers-at-once entry points (one wave per buffer)."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_crc_vs_oracle(gpu, oracle):
+    rng = np.random.default_rng(0x51F7)
+    blob = rng.integers(0, 256, size=24 << 20, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    # every length class of the wave kernel, every alignment, plus a few long ones
+    lens = list(range(0, 80)) + [127, 128, 1007, 1008, 1009, 1023, 1024, 1025, 1039, 1040, 1041,
+                                 2047, 2048, 2049, 4096, 65535, 65536, 300001, (1 << 20),
+                                 (1 << 20) + 1, (3 << 20) + 7]
+    lens = lens + [int(x) for x in rng.integers(0, 5000, size=3000)]
+    offs, pos = [], 0
+    for i, n in enumerate(lens):
+        pos += int(rng.integers(0, 19))  # ragged gaps -> every alignment
+        if pos + n > blob.size:
+            pos = int(rng.integers(0, 64))
+        offs.append(pos)
+        pos += n
+    for state, xo in ((0xFFFFFFFF, 0xFFFFFFFF), (0, 0), (0x12345678, 0)):
+        got = gpu.compute_batch(state, d, offs, lens, xor_out=xo).cpu().numpy().view(np.uint32)
+        for i, (o, n) in enumerate(zip(offs, lens)):
+            want = oracle.compute(state, blob[o:o + n]) ^ xo
+            assert int(got[i]) == want, (i, o, n, hex(int(got[i])), hex(want))
+
+
+def test_batch_empty_and_single(gpu, oracle):
+    d = torch.arange(0, 200, dtype=torch.uint8, device="cuda")
+    assert gpu.compute_batch(0xFFFFFFFF, d, [], []).numel() == 0
+    got = gpu.compute_batch(0xFFFFFFFF, d, [3], [100]).cpu().numpy().view(np.uint32)
+    assert int(got[0]) == oracle.compute(0xFFFFFFFF, d.cpu().numpy()[3:103])
+
+
+def test_read_chunks_device(gpu, oracle):
+    from sift_amd import container
+    rng = np.random.default_rng(7)
+    stream = bytearray()
+    offs, want_status, want_len = [], [], []
+    sizes = [0, 1, 3, 4, 11, 12, 13, 27, 28, 29, 500, 1012, 1013, 4096, 70000, 2_500_000] + \
+            [int(x) for x in rng.integers(0, 3000, size=500)]
+    for i, n in enumerate(sizes):
+        data = rng.integers(0, 256, size=n, dtype=np.uint8)
+        ser = bytearray(oracle.write_chunk(b"AMRG" if i % 3 else b"SEND", data))
+        kind = i % 7
+        if kind == 3 and n > 0:      # corrupt one data byte
+            ser[8 + n // 2] ^= 0x40
+            st = 5
+        elif kind == 5:              # corrupt stored crc
+            ser[-1] ^= 1
+            st = 5
+        elif kind == 6 and n > 2:    # type byte flipped
+            ser[5] ^= 0x20
+            st = 5
+        else:
+            st = 0
+        stream += bytes(int(rng.integers(0, 5)))  # ragged padding between chunks
+        offs.append(len(stream))
+        stream += ser
+        want_status.append(st)
+        want_len.append(n if st == 0 else 0)
+    # an oversize length field and a truncated chunk at the very end
+    offs.append(len(stream)); stream += struct.pack(">I", (1 << 30) + 1) + b"AMRG"; want_status.append(3); want_len.append(0)
+    offs.append(len(stream)); stream += oracle.write_chunk(b"AMRG", bytes(100))[:-3]; want_status.append(1); want_len.append(0)
+    blob = np.frombuffer(bytes(stream), dtype=np.uint8)
+    d = torch.from_numpy(blob.copy()).cuda()
+    status, dlen = container.read_chunks_device(d, offs)
+    status, dlen = status.cpu().tolist(), dlen.cpu().tolist()
+    assert status == want_status
+    assert dlen == want_len
+    # same verdicts as the oracle's Chunk::read on the same windows
+    for o, st in zip(offs, status):
+        assert oracle.read_chunk(bytes(stream), o)[0] == st
+    # windows clipped to the next chunk: a chunk cut short is Error::Read
+    avail = [b - a for a, b in zip(offs, offs[1:] + [len(stream)])]
+    avail[14] = 12 + sizes[14] - 1   # chunk 14 is intact; one byte short of its stored crc
+    avail[15] = 12 + sizes[15]       # exactly enough
+    s2, _ = container.read_chunks_device(d, offs, avail)
+    s2 = s2.cpu().tolist()
+    assert want_status[14] == 0 and s2[14] == 1
+    assert s2[:14] == want_status[:14] and s2[15:] == want_status[15:]
