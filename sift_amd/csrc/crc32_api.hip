@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -38,9 +39,8 @@ int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 constexpr int kRingSlots = 64;
-// Workspace slot, in u32 words: residues (two-launch form) | result word |
+// Workspace slot, in u32 words: residues (two-launch form) | pad |
 // u64 XOR accumulator (own 128-B line) | u64 arrival counter (own line).
-constexpr size_t kResultWord = kMaxGroups;         // sync API's result
 constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32 words on
 constexpr size_t kSlotWords = kMaxGroups + 96;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
@@ -59,12 +59,24 @@ struct DeviceCtx {
     // host-input staging (sift_crc32_compute_host)
     uint8_t* d_stage[2] = {nullptr, nullptr};
     uint32_t* d_state = nullptr;  // chained running state for staged pieces
+    // Results of the synchronous entry points land in pinned host memory the
+    // GPU writes directly (no device->host copy command): 64 slots, 64 B apart.
+    uint32_t* h_results = nullptr;
+    unsigned h_next = 0;
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     std::mutex host_path_mutex;
     // measurement support (sift_profile_begin / _end): event pairs around the
     // tile kernel of each launch, recorded on the launch's own stream
     std::vector<hipEvent_t> prof_events;
+    struct MatsEntry {
+        int64_t tpg = -1;
+        int groups = -1;
+        CombineMats m;
+    };
+    std::array<MatsEntry, 8> mats_cache;
+    unsigned mats_next = 0;
+    std::mutex mats_mutex;
     int prof_used = 0;
     int prof_stride = 1, prof_seen = 0;
     bool prof_on = false;
@@ -126,6 +138,7 @@ int get_ctx(int device, DeviceCtx** out) {
     SIFT_HIP(hipMalloc(&c->d_ring, kRingSlots * kSlotWords * sizeof(uint32_t)));
     SIFT_HIP(hipMemset(c->d_ring, 0, kRingSlots * kSlotWords * sizeof(uint32_t)));
     SIFT_HIP(hipMalloc(&c->d_state, 256));
+    SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), 64 * 64, hipHostMallocDefault));
     SIFT_HIP(hipSetDevice(prev));
     g_ctx[device] = c;
     *out = c;
@@ -145,6 +158,42 @@ struct DeviceGuard {
     }
 };
 
+// x^(-8h) mod P for h = 0..15 (P is primitive: x^-k = x^(2^32-1-k)).
+const uint32_t* xinv8() {
+    static const struct Tab {
+        uint32_t v[16];
+        Tab() {
+            for (uint64_t h = 0; h < 16; ++h) v[h] = gf2_xpow(x2n(), 0xFFFFFFFFull - 8ull * h);
+        }
+    } tab;
+    return tab.v;
+}
+
+// Matrices of z^(2^s), z = x^(8 * tpg * kTileBytes), for the group-weighting
+// step.  They depend on (tpg, groups) only, so calls of one size class reuse
+// them; a small per-device cache saves the ~10 GF(2) multiplies.
+void combine_mats(DeviceCtx* c, int64_t tpg, int groups, CombineMats* out) {
+    std::lock_guard<std::mutex> lock(c->mats_mutex);
+    for (auto& e : c->mats_cache)
+        if (e.tpg == tpg && e.groups == groups) {
+            *out = e.m;
+            return;
+        }
+    uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
+    for (int s = 0; s < kTreeLevels; ++s) {
+        uint32_t r = z;
+        for (int k = 0; k < 32; ++k) {
+            out->z[s][k] = r;
+            r = gf2_mulx(r);
+        }
+        if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
+    }
+    auto& slot = c->mats_cache[c->mats_next++ % c->mats_cache.size()];
+    slot.tpg = tpg;
+    slot.groups = groups;
+    slot.m = *out;
+}
+
 // Geometry + launch of one compute(state, buf) over device memory.
 int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, const void* d_buf,
                    uint64_t len, uint32_t xor_out, uint32_t* d_out, uint32_t* workspace,
@@ -163,14 +212,14 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
 
     FinalArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.state_ptr = d_state_in;
     f.xor_out = xor_out;
     f.out = d_out;
 
-    if (nvec == 0) {
-        // Fewer than 16 bytes, all inside one vector: one lane walks them.
-        f.xpow_body = kOne;
-        f.state_term = state;
+    if (len < 32) {
+        // Too short to hold the folded state safely inside whole vectors: one
+        // lane walks the bytes from the starting register.
+        f.state_imm = state;
+        f.state_ptr = d_state_in;
         f.tail = static_cast<const uint8_t*>(d_buf);
         f.tail_len = (uint32_t)len;
         f.groups = 0;
@@ -182,11 +231,8 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     }
 
     const uint32_t head_skip = (uint32_t)(addr & 15u);
-    const uint64_t body_bytes = (uint64_t)nvec * 16u - head_skip;
     f.tail = reinterpret_cast<const uint8_t*>(v1 << 4);
     f.tail_len = (uint32_t)((addr + len) & 15u);
-    f.xpow_body = gf2_xpow(x2n(), 8ull * body_bytes);
-    f.state_term = d_state_in ? 0u : gf2_mulmod(state, f.xpow_body);
 
     const int64_t ntile = (nvec + kTileVecs - 1) / kTileVecs;
     int64_t groups = std::min<int64_t>(ntile, c->groups_max);
@@ -205,20 +251,15 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     t.partial = workspace;
     t.exchange = workspace + kExchangeWord;
     t.head_skip = head_skip;
+    t.xinv_h = xinv8()[head_skip];
+    t.state_ptr = d_state_in;
+    t.state_fold = d_state_in ? 0u : (head_skip ? gf2_mulmod(state, t.xinv_h) : state);
     t.fuse_final = groups == 1 ? 1u : 0u;
     t.single_launch = (groups > 1 && g_single_launch) ? 1u : 0u;
 
     CombineMats m;
     if (groups > 1) {
-        uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
-        for (int s = 0; s < kTreeLevels; ++s) {
-            uint32_t r = z;
-            for (int k = 0; k < 32; ++k) {
-                m.z[s][k] = r;
-                r = gf2_mulx(r);
-            }
-            if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
-        }
+        combine_mats(c, tpg, (int)groups, &m);
     } else {
         std::memset(&m, 0, sizeof(m));
     }
@@ -237,6 +278,11 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
         SIFT_HIP(hipGetLastError());
     }
     return SIFT_OK;
+}
+
+volatile uint32_t* result_slot(DeviceCtx* c) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    return c->h_results + (size_t)(c->h_next++ % 64) * 16;
 }
 
 uint32_t* ring_slot(DeviceCtx* c) {
@@ -295,6 +341,7 @@ void sift_shutdown(void) {
         (void)hipFree(c->d_tabs);
         (void)hipFree(c->d_ring);
         (void)hipFree(c->d_state);
+        (void)hipHostFree(c->h_results);
         for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; ++i) {
             if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
@@ -389,12 +436,12 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf
         return SIFT_ERR_HIP;
     }
     uint32_t* ws = ring_slot(c);
-    uint32_t* d_res = ws + kResultWord;
+    volatile uint32_t* res = result_slot(c);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = launch_compute(c, state, nullptr, d_buf, len, 0u, d_res, ws, s);
+    rc = launch_compute(c, state, nullptr, d_buf, len, 0u, const_cast<uint32_t*>(res), ws, s);
     if (rc != SIFT_OK) return rc;
-    SIFT_HIP(hipMemcpyAsync(out, d_res, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     SIFT_HIP(hipStreamSynchronize(s));
+    *out = *res;
     return SIFT_OK;
 }
 
@@ -418,6 +465,7 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
 
     const uint8_t* src = static_cast<const uint8_t*>(buf);
     uint32_t* ws = ring_slot(c);
+    volatile uint32_t* res = result_slot(c);
     // Running state lives in c->d_state between pieces; piece 0 starts from
     // the immediate.  Empty input still runs one (empty) launch so that the
     // result provably comes from the device path.
@@ -432,16 +480,16 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
                                     c->copy_stream));
         SIFT_HIP(hipEventRecord(c->copied[b], c->copy_stream));
         SIFT_HIP(hipStreamWaitEvent(c->work_stream, c->copied[b], 0));
+        const bool last = off + n >= len;
         rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_stage[b], n, 0u,
-                            c->d_state, ws, c->work_stream);
+                            last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream);
         if (rc != SIFT_OK) return rc;
         SIFT_HIP(hipEventRecord(c->consumed[b], c->work_stream));
         off += n;
         ++piece;
     } while (off < len);
-    SIFT_HIP(hipMemcpyAsync(out, c->d_state, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                            c->work_stream));
     SIFT_HIP(hipStreamSynchronize(c->work_stream));
+    *out = *res;
     return SIFT_OK;
 }
 

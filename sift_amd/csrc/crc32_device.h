@@ -63,6 +63,16 @@ struct TileArgs {
     uint32_t* partial;         // [groups] residues, one per workgroup
     uint32_t* exchange;        // single-launch finish: u64 XOR accumulator, and 128 B on a u64
                                // arrival counter; both zero between calls
+    // Starting register, folded into the message: with h = head_skip leading
+    // zero bytes the padded message is n + h bytes long and
+    //   state * x^(8n) = (state * x^(-8h)) * x^(8(n+h)),
+    // which is the weight of the padded message's first word.  So the lane that
+    // holds vector 0 XORs state * x^(-8h) into word 0.  Immediate state: the host
+    // does the multiply (state_fold).  Device state (state_ptr): that lane does
+    // it with xinv_h = x^(-8h).
+    uint32_t state_fold;
+    uint32_t xinv_h;
+    const uint32_t* state_ptr;
     uint32_t head_skip;        // bytes of vector 0 that precede the message (zeroed)
     uint32_t fuse_final;       // groups == 1: finish in this launch, no exchange
     uint32_t single_launch;    // groups > 1: last group to arrive combines and finishes
@@ -71,9 +81,11 @@ struct TileArgs {
 // Arguments of the finishing step (combine kernel, or fused into the tile
 // kernel when one workgroup did all the work).
 struct FinalArgs {
-    uint32_t xpow_body;          // x^(8 * body_bytes): carries the incoming state across the body
-    uint32_t state_term;         // state * x^(8 * body_bytes), when the state is an immediate ...
-    const uint32_t* state_ptr;   // ... or, if non-null, where to read the state on the device
+    // Serial path only (inputs under 32 bytes, groups == 0): the starting register,
+    // as an immediate or, if state_ptr is non-null, read on the device.  On the
+    // vector path the state is folded into vector 0 by the tile kernel (TileArgs).
+    uint32_t state_imm;
+    const uint32_t* state_ptr;
     const uint8_t* tail;         // bytes after the last whole vector (or the whole tiny input)
     uint32_t tail_len;
     uint32_t xor_out;            // 0, or 0xFFFFFFFF to finalize (Chunk::compute_crc)

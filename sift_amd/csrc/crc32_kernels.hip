@@ -77,10 +77,9 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t r) {
     return r;
 }
 
-// Incoming state and trailing bytes; one lane.
+// Trailing bytes and the store; one lane.  `body` already carries the state.
 __device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f) {
-    // state * x^(8*body): folded on the host when the state is an immediate
-    uint32_t r = (f.state_ptr ? gf2_mulmod(*f.state_ptr, f.xpow_body) : f.state_term) ^ body;
+    uint32_t r = body;
     for (uint32_t i = 0; i < f.tail_len; ++i) r = crc_step_byte(r, f.tail[i]);
     *f.out = r ^ f.xor_out;
 }
@@ -122,7 +121,10 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         const int64_t vi = v0 + (int64_t)tid;
         if (vi >= 0) {
             acc = load_vec(p + tid);
-            if (vi == 0 && a.head_skip) acc = mask_head(acc, a.head_skip);
+            if (vi == 0) {
+                if (a.head_skip) acc = mask_head(acc, a.head_skip);
+                acc[0] ^= a.state_ptr ? gf2_mulmod(*a.state_ptr, a.xinv_h) : a.state_fold;
+            }
         }
         p += kTileVecs;
         --ntiles;
@@ -302,7 +304,11 @@ __global__ __launch_bounds__(kMaxGroups) void crc32_combine_kernel(const uint32_
         }
     }
     __syncthreads();
-    if (tid == 0) finish(G > 0 ? sh[0] : 0u, f);
+    if (tid == 0) {
+        // G == 0: serial path, the whole (< 32 byte) input is the "tail"
+        const uint32_t start = f.state_ptr ? *f.state_ptr : f.state_imm;
+        finish(G > 0 ? sh[0] : start, f);
+    }
 }
 
 

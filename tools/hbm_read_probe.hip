@@ -56,6 +56,45 @@ __global__ __launch_bounds__(1024) void read_runs(const u32x4* base, size_t tile
     if (r == 0x12345678u) out[blockIdx.x] = r;  // keeps the loads alive
 }
 
+// Round-robin tiles: workgroup g reads tiles g, g+G, g+2G, ... (the whole chip
+// sweeps the buffer front to back together).
+template <int U>
+__global__ __launch_bounds__(1024) void read_roundrobin(const u32x4* base, size_t tiles, uint32_t* out) {
+    const size_t G = gridDim.x;
+    const u32x4* p = base + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    size_t t = blockIdx.x;
+    for (; t + (U - 1) * G < tiles; t += U * G) {
+        u32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(p + (t + u * G) * 1024);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= w[u];
+    }
+    for (; t < tiles; t += G) acc ^= p[t * 1024];
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;
+}
+
+// Contiguous runs, but each wave owns its own run (4096 streams instead of 256).
+template <int U>
+__global__ __launch_bounds__(1024) void read_wave_runs(const u32x4* base, size_t vec_per_wave, uint32_t* out) {
+    const size_t wave = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const u32x4* p = base + wave * vec_per_wave + (threadIdx.x & 63);
+    u32x4 acc = {0, 0, 0, 0};
+    size_t t = 0;
+    const size_t n = vec_per_wave / 64;
+    for (; t + U <= n; t += U) {
+        u32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(p + (t + u) * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= w[u];
+    }
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;
+}
+
 // Conventional streaming read: 256-lane workgroups, grid-stride.
 template <bool NT>
 __global__ __launch_bounds__(256) void read_gridstride(const u32x4* base, size_t nvec, uint32_t* out) {
@@ -114,8 +153,10 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     const char* names[] = {"read_runs<4,nt>  (crc geometry)", "read_runs<8,nt>", "read_runs<4,plain>",
                            "gridstride 256x2048 nt", "gridstride 256x4096 plain",
-                           "sift tile kernel (events)", "sift compute, whole call"};
-    const int nv = 7;
+                           "sift tile kernel (events)", "sift compute, whole call",
+                           "read_runs<2,nt>", "roundrobin<2> 256 groups", "roundrobin<4> 256 groups",
+                           "wave_runs<4> 4096 streams", "read_runs<4,nt> 512 groups"};
+    const int nv = 12;
     std::vector<std::vector<float>> ms(nv);
     for (int r = 0; r < rounds + 3; ++r) {
         for (int v = 0; v < nv; ++v) {
@@ -138,6 +179,11 @@ int main(int argc, char** argv) {
                     case 6:
                         sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, buf, n, out, nullptr, nullptr);
                         break;
+                    case 7: read_runs<2, true><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 8: read_roundrobin<2><<<256, 1024>>>((const u32x4*)buf, tiles, out); break;
+                    case 9: read_roundrobin<4><<<256, 1024>>>((const u32x4*)buf, tiles, out); break;
+                    case 10: read_wave_runs<4><<<256, 1024>>>((const u32x4*)buf, nvec / 4096, out); break;
+                    case 11: read_runs<4, true><<<512, 1024>>>((const u32x4*)buf, tpg / 2, out); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
