@@ -168,7 +168,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (GF(2) polynomial arithmetic over u8 input)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {
                 "workload": workload,

@@ -9,13 +9,16 @@
 //
 //   reg(s, M) = s * x^(8|M|)  +  sum_j  w_j * x^(32 * (words after j) + 32)
 //
-// Tile kernel: each workgroup owns a contiguous run of 16 KiB tiles and folds
-// it to one 32-bit residue.  HBM-bound by design: one coalesced, non-temporal
-// dwordx4 load per lane per tile, 16 LDS lookups and ~50 VALU ops per load.
-// The tables sit in LDS replicated once per bank so that a lookup with 32
-// different indices in a half-wave is conflict-free.
-// Combine kernel: log-depth tree over the <= 1024 residues, then the incoming
-// state and the < 16 trailing bytes.
+// crc32_tiles_kernel   one buffer, whole chip.  Each workgroup owns a
+//     contiguous run of 16 KiB tiles and folds it to one 32-bit residue.
+//     HBM-bound by design: one coalesced, non-temporal dwordx4 load per lane
+//     per tile, 16 LDS lookups and ~50 VALU ops per load.  The tables sit in
+//     LDS replicated once per bank so that a lookup with 32 different indices
+//     in a half-wave is conflict-free.  The workgroups exchange residues
+//     through two 64-bit atomics; the last to arrive finishes (single launch).
+// crc32_batch_kernel   many buffers, one wave per buffer (also Chunk::read x n).
+// crc32_combine_kernel inputs under 32 bytes (one lane), and the second launch
+//     of the two-launch A/B form (tree over the <= 1024 residues).
 #include <hip/hip_runtime.h>
 
 #include "crc32_device.h"
