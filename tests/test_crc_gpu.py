@@ -172,3 +172,47 @@ def test_back_to_back_calls_share_workspace(gpu, oracle):
     got = [int(v) & 0xFFFFFFFF for v in outs.cpu().tolist()]
     want = [oracle.compute(0xFFFFFFFF, b) for b in bufs]
     assert got == want * 5
+
+
+def test_beyond_4gib_offsets(gpu):
+    # 64-bit lengths: 5 GiB + 3 bytes, cut on both sides of the 4 GiB mark
+    n = (5 << 30) + 3
+    t = torch.empty(n, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(SEED)
+    for a in range(0, n, 1 << 30):
+        b = min(n, a + (1 << 30))
+        t[a:b] = torch.randint(0, 256, (b - a,), dtype=torch.uint8, device="cuda", generator=g)
+    whole = gpu.compute(0xFFFFFFFF, t)
+    for cut in ((4 << 30) - 1, (4 << 30) + 17):
+        sa = gpu.compute(0xFFFFFFFF, t[:cut])
+        assert gpu.compute(sa, t[cut:]) == whole, cut
+        assert gpu.concat(sa, gpu.compute(0, t[cut:]), n - cut) == whole, cut
+    h = t.cpu().numpy()
+    del t
+    crc = 0
+    for a in range(0, n, 1 << 30):
+        crc = zlib.crc32(h[a:a + (1 << 30)], crc)
+    assert whole ^ 0xFFFFFFFF == crc
+
+
+def test_graph_capture_and_replay(gpu, oracle):
+    # The device entry point allocates nothing and never synchronises, so it can be
+    # captured into a HIP graph and replayed on new data in the same buffers.
+    buf = _rand((6 << 20) + 123, seed=21)
+    d = torch.from_numpy(buf).cuda()
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(gpu.workspace_bytes(), dtype=torch.uint8, device="cuda")
+    gpu.compute_async(0xFFFFFFFF, d[7:], out[0:1], ws)  # first-use initialisation outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gpu.compute_async(0xFFFFFFFF, d[7:], out[0:1], ws)
+        gpu.compute_async(out[0:1], d[:1000], out[1:2], ws)
+    for seed in (22, 23, 24):
+        nb = _rand(buf.size, seed=seed)
+        d.copy_(torch.from_numpy(nb).cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [int(v) & 0xFFFFFFFF for v in out.cpu().tolist()]
+        s0 = oracle.compute(0xFFFFFFFF, nb[7:])
+        assert got == [s0, oracle.compute(s0, nb[:1000])], seed
