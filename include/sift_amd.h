@@ -159,13 +159,24 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  *                           SIFT_ERR_READ_INVALID_CHUNK_SIZE or
  *                           SIFT_ERR_READ_CRC_MISMATCH, raised in the reference's
  *                           order; d_data_len[i] (optional, may be NULL) = data
- *                           length of chunk i if it parsed, else 0. */
+ *                           length of chunk i if it parsed, else 0.
+ * sift_read_documents_device: the framing of read_document (document.rs:62-77)
+ *                           on n whole save files: read_header, read_chunk +
+ *                           expect_type(AMRG), read_chunk + expect_type(SEND).
+ *                           The automerge decode between them is NOT done
+ *                           (third-party codec, out of scope).  d_status[i] as
+ *                           above (a wrong chunk type or bad magic is
+ *                           SIFT_ERR_READ); d_amrg_len[i] (optional) = length of
+ *                           the AMRG payload, which starts 17 bytes into file i. */
 int sift_crc32_batch_device(int device, uint32_t state, uint32_t xor_out, const void *d_base,
                             const uint64_t *offsets, const uint64_t *lens, uint32_t n,
                             uint32_t *d_out, void *stream);
 int sift_read_chunks_device(int device, const void *d_base, const uint64_t *offsets,
                             const uint64_t *avail, uint32_t n, uint32_t *d_status,
                             uint32_t *d_data_len, void *stream);
+int sift_read_documents_device(int device, const void *d_base, const uint64_t *offsets,
+                               const uint64_t *avail, uint32_t n, uint32_t *d_status,
+                               uint32_t *d_amrg_len, void *stream);
 
 /* ------------------------------------------- container.rs:104-126 --------
  * write_header / read_header on byte slices.  Return bytes written/consumed

@@ -104,22 +104,32 @@ def read_chunk(reader, pos: int = 0, device: int | None = None):
     return Chunk(bytes(t), a[start:start + ln.value].tobytes()), pos + int(n)
 
 
+def _batch(fn, base: torch.Tensor, offsets, avail):
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    av = (np.uint64(base.numel()) - off) if avail is None else np.ascontiguousarray(avail, dtype=np.uint64)
+    if off.size and int((off + av).max()) > base.numel():
+        raise ValueError("a window reaches past the end of base")
+    dev = base.device.index
+    status = torch.empty(off.size, dtype=torch.int32, device=base.device)
+    dlen = torch.empty(off.size, dtype=torch.int32, device=base.device)
+    st = fn(dev, base.data_ptr(), off.ctypes.data, av.ctypes.data, off.size, status.data_ptr(),
+            dlen.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if st != _lib.OK:
+        raise _lib.SiftError(st)
+    return status, dlen
+
+
+def read_documents_device(base: torch.Tensor, offsets, avail=None):
+    """The framing of read_document (document.rs:62-77) on n save files resident
+    in `base`: header, AMRG chunk, SEND chunk, CRCs verified; the automerge
+    decode is not done.  Returns (status, amrg_len) int32 device tensors."""
+    return _batch(lib.sift_read_documents_device, base, offsets, avail)
+
+
 def read_chunks_device(base: torch.Tensor, offsets, avail=None):
     """Chunk::read (container.rs:47-66) on n serialized chunks resident in the
     device tensor `base`, one wave per chunk.  `offsets` is a host sequence of
     chunk starts; `avail[i]` the bytes readable from offsets[i] (default: to the
     end of `base`).  Returns (status, data_len) int32 device tensors; status is
     0 or the reference's error as in include/sift_amd.h.  Asynchronous."""
-    off = np.ascontiguousarray(offsets, dtype=np.uint64)
-    av = (np.uint64(base.numel()) - off) if avail is None else np.ascontiguousarray(avail, dtype=np.uint64)
-    if off.size and int((off + av).max()) > base.numel():
-        raise ValueError("a chunk window reaches past the end of base")
-    dev = base.device.index
-    status = torch.empty(off.size, dtype=torch.int32, device=base.device)
-    dlen = torch.empty(off.size, dtype=torch.int32, device=base.device)
-    st = lib.sift_read_chunks_device(dev, base.data_ptr(), off.ctypes.data, av.ctypes.data, off.size,
-                                     status.data_ptr(), dlen.data_ptr(),
-                                     torch.cuda.current_stream(dev).cuda_stream)
-    if st != _lib.OK:
-        raise _lib.SiftError(st)
-    return status, dlen
+    return _batch(lib.sift_read_chunks_device, base, offsets, avail)

@@ -530,7 +530,7 @@ namespace {
 constexpr uint64_t kBatchWaveMax = 1ull << 20;
 
 int run_batch(int device, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
-              uint32_t n, uint32_t state, uint32_t xor_out, bool verify, uint32_t* d_out,
+              uint32_t n, uint32_t state, uint32_t xor_out, int verify, uint32_t* d_out,
               uint32_t* d_data_len, hipStream_t stream) {
     if (n == 0) return SIFT_OK;
     if (!offsets || !lens || !d_out || !d_base) {
@@ -561,7 +561,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     b.n = n;
     b.state = state;
     b.xor_out = xor_out;
-    b.verify = verify ? 1u : 0u;
+    b.verify = (uint32_t)verify;
     b.chunk_limit = SIFT_CHUNK_SIZE_LIMIT;
     b.out = d_out;
     b.data_len = d_data_len;
@@ -588,14 +588,21 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
 int sift_crc32_batch_device(int device, uint32_t state, uint32_t xor_out, const void* d_base,
                             const uint64_t* offsets, const uint64_t* lens, uint32_t n,
                             uint32_t* d_out, void* stream) {
-    return run_batch(device, d_base, offsets, lens, n, state, xor_out, false, d_out, nullptr,
+    return run_batch(device, d_base, offsets, lens, n, state, xor_out, 0, d_out, nullptr,
                      static_cast<hipStream_t>(stream));
 }
 
 int sift_read_chunks_device(int device, const void* d_base, const uint64_t* offsets,
                             const uint64_t* avail, uint32_t n, uint32_t* d_status,
                             uint32_t* d_data_len, void* stream) {
-    return run_batch(device, d_base, offsets, avail, n, 0, 0, true, d_status, d_data_len,
+    return run_batch(device, d_base, offsets, avail, n, 0, 0, 1, d_status, d_data_len,
+                     static_cast<hipStream_t>(stream));
+}
+
+int sift_read_documents_device(int device, const void* d_base, const uint64_t* offsets,
+                               const uint64_t* avail, uint32_t n, uint32_t* d_status,
+                               uint32_t* d_amrg_len, void* stream) {
+    return run_batch(device, d_base, offsets, avail, n, 0, 0, 2, d_status, d_amrg_len,
                      static_cast<hipStream_t>(stream));
 }
 

@@ -415,6 +415,26 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
 }
 
+// Chunk::read (container.rs:47-66) by one wave on the serialized chunk at ptr,
+// `avail` bytes readable.  Returns SIFT_OK (0), Error::Read (1),
+// ReadInvalidChunkSize (3) or ReadCrcMismatch (5), raised in the reference's
+// order; *dlen is the chunk's data length once the length field has been read.
+__device__ __forceinline__ uint32_t read_chunk_wave(const uint8_t* ptr, uint64_t avail,
+                                                    uint32_t limit, uint32_t* dlen,
+                                                    const uint32_t* ldsY, const uint32_t* ldsX,
+                                                    uint32_t lane, uint32_t lane32, uint32_t aw) {
+    *dlen = 0;
+    if (avail < 4) return 1;                      // read_u32 fails, :48
+    const uint32_t n = be32(ptr);
+    if (n > limit) return 3;                      // :49-52
+    *dlen = n;
+    if (avail < 12ull + (uint64_t)n) return 1;    // read_exact on type / data / crc fails, :54-60
+    // container.rs:79-84: digest over type | data = ptr[4 .. 8+n), finalized
+    const uint32_t crc =
+        wave_crc(ptr + 4, 4ull + n, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
+    return crc == be32(ptr + 8 + n) ? 0u : 5u;    // :60-63
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
@@ -441,24 +461,46 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             if (lane == 0) b.out[i] = r ^ b.xor_out;
             continue;
         }
-        // Chunk::read (container.rs:47-66) on the serialized chunk at ptr, it.len bytes available.
-        uint32_t status = 0, dlen = 0;
-        if (it.len < 4) {
-            status = 1;  // Error::Read
+        if (b.verify == 1) {
+            // Chunk::read x n
+            uint32_t dlen = 0;
+            const uint32_t status = read_chunk_wave(ptr, it.len, b.chunk_limit, &dlen, ldsY, ldsX,
+                                                    lane, lane32, aw);
+            if (lane == 0) {
+                b.out[i] = status;
+                if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
+            }
+            continue;
+        }
+        // read_document's framing (document.rs:62-77): header, a chunk that must
+        // be AMRG, a chunk that must be SEND.  Each read_chunk verifies its CRC
+        // before expect_type looks at the type, as in the reference.
+        uint32_t status = 0, amrg_len = 0, dlen = 0;
+        uint64_t pos = 0;
+        if (it.len < 9u) {
+            status = 1;  // read_exact on the header fails (container.rs:109)
         } else {
-            dlen = be32(ptr);
-            if (dlen > b.chunk_limit) status = 3;                  // ReadInvalidChunkSize, :49-52
-            else if (it.len < 12ull + (uint64_t)dlen) status = 1;  // read_exact fails, :54-60
+            const uint8_t magic[9] = {0x89, 0x53, 0x49, 0x46, 0x54, 0x0D, 0x0A, 0x1A, 0x0A};
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (ptr[k] != magic[k]) status = 1;  // InvalidData (container.rs:113)
+            pos = 9;
         }
         if (status == 0) {
-            // container.rs:79-84: digest over type | data = ptr[4 .. 8+dlen), finalized
-            const uint32_t crc =
-                wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
-            if (crc != be32(ptr + 8 + dlen)) status = 5;           // ReadCrcMismatch, :60-63
+            status = read_chunk_wave(ptr + pos, it.len - pos, b.chunk_limit, &dlen, ldsY, ldsX, lane,
+                                     lane32, aw);
+            if (status == 0 && be32(ptr + pos + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
+            amrg_len = dlen;
+            pos += 12ull + dlen;
+        }
+        if (status == 0) {
+            status = read_chunk_wave(ptr + pos, it.len - pos, b.chunk_limit, &dlen, ldsY, ldsX, lane,
+                                     lane32, aw);
+            if (status == 0 && be32(ptr + pos + 4) != 0x53454E44u) status = 1;  // expect_type(SEND)
         }
         if (lane == 0) {
             b.out[i] = status;
-            if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
+            if (b.data_len) b.data_len[i] = status == 0 ? amrg_len : 0u;
         }
     }
 }

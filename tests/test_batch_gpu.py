@@ -85,3 +85,59 @@ def test_read_chunks_device(gpu, oracle):
     s2 = s2.cpu().tolist()
     assert want_status[14] == 0 and s2[14] == 1
     assert s2[:14] == want_status[:14] and s2[15:] == want_status[15:]
+
+
+def test_read_documents_device(gpu, oracle):
+    # document.rs:53-77 framing on many files at once, against the oracle's
+    # read_header / read_chunk / type checks applied in the reference's order
+    from oracle import py_oracle
+    from sift_amd import container
+    rng = np.random.default_rng(11)
+
+    def make(payload, mutate):
+        f = bytearray(py_oracle.HEADER + oracle.write_chunk(b"AMRG", payload) + oracle.write_chunk(b"SEND", b""))
+        if mutate == 1:
+            f[3] ^= 0x01                       # bad magic
+        elif mutate == 2 and len(payload):
+            f[17 + len(payload) // 2] ^= 0x80  # payload bit flip
+        elif mutate == 3:
+            f = bytearray(py_oracle.HEADER + oracle.write_chunk(b"SEND", payload) + oracle.write_chunk(b"SEND", b""))
+        elif mutate == 4:
+            f = bytearray(py_oracle.HEADER + oracle.write_chunk(b"AMRG", payload) + oracle.write_chunk(b"AMRG", b""))
+        elif mutate == 5:
+            f = f[:-2]                         # truncated SEND chunk
+        elif mutate == 6:
+            f[-1] ^= 0x04                      # SEND crc damaged
+        elif mutate == 7:
+            f = f[:5]                          # shorter than the header
+        elif mutate == 8:
+            f += b"trailing bytes are ignored by read_document"
+        return bytes(f)
+
+    def expect(f):
+        try:
+            pos = py_oracle.read_header(f)
+            t, d, pos = py_oracle.read_chunk(f, pos)
+            if t != b"AMRG":
+                raise py_oracle.ContainerError("Read")
+            t2, _, pos = py_oracle.read_chunk(f, pos)
+            if t2 != b"SEND":
+                raise py_oracle.ContainerError("Read")
+            return 0, len(d)
+        except py_oracle.ContainerError as e:
+            return {"Read": 1, "ReadInvalidChunkSize": 3, "ReadCrcMismatch": 5}[e.kind], 0
+
+    files, offs, avail, want = bytearray(), [], [], []
+    for i in range(400):
+        n = int(rng.integers(0, 6000)) if i % 50 else 1_200_000
+        f = make(rng.integers(0, 256, size=n, dtype=np.uint8).tobytes(), i % 9)
+        files += bytes(int(rng.integers(0, 7)))
+        offs.append(len(files))
+        avail.append(len(f))
+        files += f
+        want.append(expect(f))
+    d = torch.from_numpy(np.frombuffer(bytes(files), dtype=np.uint8).copy()).cuda()
+    status, alen = container.read_documents_device(d, offs, avail)
+    got = list(zip(status.cpu().tolist(), alen.cpu().tolist()))
+    assert got == want
+    assert {w[0] for w in want} == {0, 1, 5}
