@@ -471,6 +471,23 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     const uint8_t* src = static_cast<const uint8_t*>(buf);
     uint32_t* ws = ring_slot(c);
     volatile uint32_t* res = result_slot(c);
+
+    // Pinned (hipHostMalloc / hipHostRegister) input is device-addressable: the
+    // tile kernel streams it over PCIe directly, each byte crossing once, with
+    // no staging copy.  Pageable input is staged below.
+    if (len >= 4096) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeHost &&
+            attr.devicePointer != nullptr) {
+            rc = launch_compute(c, state, nullptr, attr.devicePointer, len, 0u,
+                                const_cast<uint32_t*>(res), ws, c->work_stream);
+            if (rc != SIFT_OK) return rc;
+            SIFT_HIP(hipStreamSynchronize(c->work_stream));
+            *out = *res;
+            return SIFT_OK;
+        }
+        (void)hipGetLastError();  // an unregistered pointer is not an error here
+    }
     // Running state lives in c->d_state between pieces; piece 0 starts from
     // the immediate.  Empty input still runs one (empty) launch so that the
     // result provably comes from the device path.

@@ -216,3 +216,13 @@ def test_graph_capture_and_replay(gpu, oracle):
         got = [int(v) & 0xFFFFFFFF for v in out.cpu().tolist()]
         s0 = oracle.compute(0xFFFFFFFF, nb[7:])
         assert got == [s0, oracle.compute(s0, nb[:1000])], seed
+
+
+def test_pinned_host_input_is_streamed_in_place(gpu, oracle):
+    # hipHostMalloc'ed input: no staging copy, the kernel reads host memory directly
+    n = (40 << 20) + 7
+    t = torch.empty(n, dtype=torch.uint8).pin_memory()
+    buf = _rand(n, seed=31)
+    t.numpy()[:] = buf
+    for a, b in ((0, n), (3, n - 5), (4097, 4097 + 5000)):
+        assert gpu.compute(0xFFFFFFFF, t.numpy()[a:b]) == oracle.compute(0xFFFFFFFF, buf[a:b])
