@@ -127,3 +127,21 @@ def test_python_mirror_shape():
     for name in ("Chunk", "Error", "read_header", "write_header", "read_chunk", "write_chunk", "HEADER"):
         assert hasattr(container, name)
     assert {"new", "update", "finalize"} - {"new"} <= set(dir(sift_amd.Digest))
+
+
+def test_header_is_plain_c_and_links(L, tmp_path):
+    exe = tmp_path / "abi_link"
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_link.c"),
+                    "-L", libdir, "-lsift_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    env = dict(os.environ)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + torch_lib + ":" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi_link ok" in r.stdout
+    # the C file lists every declared symbol
+    src = open(os.path.join(ROOT, "tests", "abi_link.c")).read()
+    for name in _declared():
+        assert name in src, name

@@ -226,3 +226,37 @@ def test_pinned_host_input_is_streamed_in_place(gpu, oracle):
     t.numpy()[:] = buf
     for a, b in ((0, n), (3, n - 5), (4097, 4097 + 5000)):
         assert gpu.compute(0xFFFFFFFF, t.numpy()[a:b]) == oracle.compute(0xFFFFFFFF, buf[a:b])
+
+
+def test_two_threads_two_streams(gpu, oracle):
+    # Calls in flight at the same time on one device: each thread has its own
+    # stream and its own zeroed workspace, as include/sift_amd.h requires.
+    import threading
+    bufs = [_rand((9 << 20) + 11 * i, seed=40 + i) for i in range(2)]
+    want = [oracle.compute(0xFFFFFFFF, b) for b in bufs]
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d = torch.from_numpy(bufs[i]).cuda()
+                ws = torch.zeros(gpu.workspace_bytes(), dtype=torch.uint8, device="cuda")
+                out = torch.zeros(200, dtype=torch.int32, device="cuda")
+                stream.synchronize()
+                for k in range(200):
+                    gpu.compute_async(0xFFFFFFFF, d, out[k:k + 1], ws)
+                stream.synchronize()
+                got = {int(v) & 0xFFFFFFFF for v in out.cpu().tolist()}
+            if got != {want[i]}:
+                errors.append((i, [hex(g) for g in got], hex(want[i])))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
