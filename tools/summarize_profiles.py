@@ -26,7 +26,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(GO, pattern))
     if not hits:
         raise SystemExit(f"missing {pattern}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # gpurun merges runs into one tree: take the newest
 
 
 # kernel-trace --stats summary: keep our kernels verbatim, shorten torch's names
