@@ -164,7 +164,11 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     }
 
     // Tables: global (L2-resident, 8 KiB) -> LDS.
+#if defined(SIFT_ABLATE_FILL)
+    if (USE_Y && tid == 5000) {
+#else
     if (USE_Y) {
+#endif
 #pragma unroll 16
         for (int i = 0; i < kYWords / kThreads; ++i)
             ldsY[i * kThreads + tid] = a.tabs->Y[i * (kThreads / kRepl) + (tid >> kReplLog2)];
@@ -209,7 +213,11 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+#if defined(SIFT_ABLATE_MULMOD)  // timing-only build (tools/): wrong results by design
+    r ^= kt;
+#else
     r = gf2_mulmod(r, kt);
+#endif
     r = wave_xor(r);
     if ((tid & 63u) == 0) red[tid >> 6] = r;
     __syncthreads();
@@ -230,6 +238,9 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // set; each factor applied by the half-wave together (lane k holds row k).
     const uint32_t G = (uint32_t)f.groups;
     const uint32_t h = G - 1u - (uint32_t)g;
+#if defined(SIFT_ABLATE_WEIGHT)
+    x ^= rows[0] ^ h;
+#else
 #pragma unroll
     for (int s = 0; s < kTreeLevels; ++s) {
         if ((h >> s) & 1u) {  // uniform
@@ -239,7 +250,12 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
             x = t;
         }
     }
+#endif
 
+#if defined(SIFT_ABLATE_EXCHANGE)
+    if (tid == 0) a.partial[g] = x;
+    return;
+#endif
     // Exchange through two 8-byte agent-scope read-modify-write atomics, both
     // sides (guide: Guideline 16 / microarch "Valid forms": atomics execute at
     // the memory side, so neither L1 nor a per-XCD L2 can serve a stale copy

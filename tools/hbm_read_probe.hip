@@ -221,6 +221,28 @@ int main(int argc, char** argv) {
         std::printf("floor: empty 256x1024 kernel median %6.2f us; one load + reduce + atomic per group %6.2f us\n",
                     t0[10] * 1e3, t1[10] * 1e3);
     }
+    // Does a power-of-two distance between the 256 streams matter?  Same kernel,
+    // runs of 255 / 256 / 253 / 251 tiles (GB/s on the bytes actually read).
+    {
+        const size_t tp[4] = {255, 256, 253, 251};  // never more than tpg: the buffer holds 256 runs of tpg tiles
+        for (int v = 0; v < 4; ++v) {
+            if (tp[v] > tpg) continue;  // would read past the buffer
+            std::vector<float> tt;
+            for (int r = 0; r < 12; ++r) {
+                float t;
+                CK(hipEventRecord(e0));
+                read_runs<2, true><<<256, 1024>>>((const u32x4*)buf, tp[v], out);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&t, e0, e1));
+                if (r >= 2) tt.push_back(t);
+            }
+            std::sort(tt.begin(), tt.end());
+            const double bytes = 256.0 * tp[v] * 16384.0;
+            std::printf("stream spacing: runs of %zu tiles  median %7.2f us  %7.1f GB/s\n", tp[v],
+                        tt[5] * 1e3, bytes / (tt[5] * 1e-3) / 1e9);
+        }
+    }
     // Fixed cost of a call: same grid, 2 tiles per group (table fill + tail +
     // exchange, almost no streaming), and 1 tile per group (no y table).
     {
