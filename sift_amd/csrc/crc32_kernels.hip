@@ -54,6 +54,17 @@ __device__ __forceinline__ uint32_t mul_x32(uint32_t v, const uint32_t* ldsX) {
            ldsX[768 + (v >> 24)];
 }
 
+// One Horner step for a lane's four words: acc <- acc * y + w.
+#ifndef SIFT_ABLATE_WORDS
+#define SIFT_ABLATE_WORDS 4  // timing-only builds thin the step to fewer real multiplies
+#endif
+__device__ __forceinline__ void horner_step(u32x4& acc, const u32x4 w, const uint32_t* ldsY,
+                                            uint32_t lane32) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        acc[c] = (c < SIFT_ABLATE_WORDS ? mul_y(acc[c], ldsY, lane32) : acc[c]) ^ w[c];
+}
+
 __device__ __forceinline__ u32x4 load_vec(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
 // One lane's vector of a whole tile: buffer_load_dwordx4, non-temporal (the
@@ -174,7 +185,16 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
             ldsY[i * kThreads + tid] = a.tabs->Y[i * (kThreads / kRepl) + (tid >> kReplLog2)];
     }
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = a.tabs->X[i];
-    const uint32_t kt = a.tabs->Kt[tid];
+    // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its
+    // multiplication matrix: computed here, while the first loads are in flight
+    // and the VALU is idle, and kept in registers through the main loop, so that
+    // the multiply at the end is 3 instructions per bit instead of 7.
+    uint32_t kb[32];
+    kb[0] = a.tabs->Kt[tid];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));  // pin: do not sink past the loop
     __syncthreads();
 
     if (USE_Y) {
@@ -186,25 +206,18 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
                 soff += U * kTileBytes;
                 ntiles -= U;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ cur[u][c];
-                }
+                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
 #pragma unroll
                 for (int u = 0; u < U; ++u) cur[u] = nxt[u];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ cur[u][c];
-            }
+            for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
         }
         while (ntiles > 0) {
             u32x4 w = load_tile(srd, voff, soff);
             soff += kTileBytes;
             --ntiles;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
+            horner_step(acc, w, ldsY, lane32);
         }
     }
 
@@ -214,9 +227,14 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
 #if defined(SIFT_ABLATE_MULMOD)  // timing-only build (tools/): wrong results by design
-    r ^= kt;
+    r ^= kb[0] ^ kb[31];
 #else
-    r = gf2_mulmod(r, kt);
+    {
+        uint32_t prod = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) prod ^= kb[i] & (0u - ((r >> (31 - i)) & 1u));
+        r = prod;
+    }
 #endif
     r = wave_xor(r);
     if ((tid & 63u) == 0) red[tid >> 6] = r;
@@ -391,9 +409,8 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     int64_t left = ntile - 1;
     const u32x4* p = vbase + vi;
     if (left > 0) {
-        u32x4 w = fold_state(*p, vi, h, state);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
+        const u32x4 w = fold_state(*p, vi, h, state);
+        horner_step(acc, w, ldsY, lane32);
         p += 64;
         --left;
     }
@@ -401,15 +418,12 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
         u32x4 w0 = __builtin_nontemporal_load(p);
         u32x4 w1 = __builtin_nontemporal_load(p + 64);
         p += 128;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w0[c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w1[c];
+        horner_step(acc, w0, ldsY, lane32);
+        horner_step(acc, w1, ldsY, lane32);
     }
     if (left > 0) {
-        u32x4 w = __builtin_nontemporal_load(p);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mul_y(acc[c], ldsY, lane32) ^ w[c];
+        const u32x4 w = __builtin_nontemporal_load(p);
+        horner_step(acc, w, ldsY, lane32);
     }
     uint32_t r = 0;
 #pragma unroll

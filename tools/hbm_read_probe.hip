@@ -136,6 +136,10 @@ __global__ __launch_bounds__(1024) void one_tile_atomic(const u32x4* base, unsig
 int main(int argc, char** argv) {
     const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 0) : (size_t)1 << 30;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 30;
+    if (n < ((size_t)64 << 20) || n % ((size_t)256 * 1024 * 16) != 0) {
+        std::fprintf(stderr, "bytes must be a multiple of 4 MiB and at least 64 MiB\n");
+        return 2;  // every kernel below assumes 256 whole runs of whole tiles inside the buffer
+    }
     CK(hipSetDevice(0));
     uint8_t* buf;
     uint32_t* out;
