@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsift_amd.so")
+# SIFT_AMD_LIB selects another build of the same library (A/B runs of -DSIFT_* variants)
+LIB_PATH = os.environ.get("SIFT_AMD_LIB") or os.path.join(_HERE, "libsift_amd.so")
 
 # status codes (include/sift_amd.h)
 OK = 0

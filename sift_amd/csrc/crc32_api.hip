@@ -96,6 +96,11 @@ void build_tables(DeviceTables* t) {
     const uint32_t y1 = gf2_xpow(x2n(), 8ull * 1024);
     for (int k = 0; k < 4; ++k)
         for (uint32_t b = 0; b < 256; ++b) t->Y1[k * 256 + b] = gf2_mulmod(b << (8 * k), y1);
+    uint32_t c1 = gf2_xpow(x2n(), 128ull * kThreads);
+    for (int i = 0; i < 32; ++i) {
+        t->C1[i] = c1;
+        c1 = gf2_mulx(c1);
+    }
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {

@@ -26,13 +26,17 @@ namespace sift {
 #ifndef SIFT_UNROLL
 #define SIFT_UNROLL 2
 #endif
+#ifndef SIFT_VPL
+#define SIFT_VPL 1
+#endif
 #ifndef SIFT_GROUPS_PER_CU
 #define SIFT_GROUPS_PER_CU 1
 #endif
 
 constexpr int kThreads = SIFT_THREADS;      // lanes per workgroup
-constexpr int kTileVecs = kThreads;         // 16-byte vectors per tile
-constexpr int kTileBytes = kThreads * 16;   // 16 KiB at 1024 lanes
+constexpr int kVpl = SIFT_VPL;              // vectors per lane per tile (independent Horner chains)
+constexpr int kTileVecs = kThreads * kVpl;  // 16-byte vectors per tile; lane t holds vectors t + j*kThreads
+constexpr int kTileBytes = kTileVecs * 16;  // 16 KiB at 1024 lanes x 1 vector
 constexpr int kRepl = SIFT_REPL;            // LDS copies of each table row (32 = one per bank)
 constexpr int kReplLog2 = kRepl == 32 ? 5 : kRepl == 16 ? 4 : kRepl == 8 ? 3 : -1;
 constexpr int kUnroll = SIFT_UNROLL;        // tiles in flight per lane, twice (current + next batch)
@@ -50,6 +54,7 @@ struct DeviceTables {
     uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
+    uint32_t C1[32];         // C1[i] = x^(128*kThreads) * x^i: from one of a lane's vectors to its next
 };
 
 // Arguments of the tile kernel.

@@ -123,7 +123,11 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     if (tv0 < a.pad_tiles) tv0 = a.pad_tiles;
     int64_t ntiles = tv1 - tv0;
 
-    u32x4 acc = {0u, 0u, 0u, 0u};
+    // A lane holds kVpl vectors of a tile (vector t + j*kThreads for j < kVpl),
+    // each with its own four running words: kVpl independent Horner chains.
+    u32x4 acc[kVpl];
+#pragma unroll
+    for (int j = 0; j < kVpl; ++j) acc[j] = u32x4{0u, 0u, 0u, 0u};
     // `p` is the tile's first vector: the same for every lane, so it and its
     // increments live in scalar registers and each load is base + lane offset.
     const u32x4* p = a.vbase;
@@ -132,12 +136,15 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         // can start before vector 0.
         const int64_t v0 = a.nvec - (a.virtual_tiles - tv0) * (int64_t)kTileVecs;
         p = a.vbase + v0;
-        const int64_t vi = v0 + (int64_t)tid;
-        if (vi >= 0) {
-            acc = load_vec(p + tid);
-            if (vi == 0) {
-                if (a.head_skip) acc = mask_head(acc, a.head_skip);
-                acc[0] ^= a.state_ptr ? gf2_mulmod(*a.state_ptr, a.xinv_h) : a.state_fold;
+#pragma unroll
+        for (int j = 0; j < kVpl; ++j) {
+            const int64_t vi = v0 + (int64_t)(j * kThreads) + (int64_t)tid;
+            if (vi >= 0) {
+                acc[j] = load_vec(p + j * kThreads + tid);
+                if (vi == 0) {
+                    if (a.head_skip) acc[j] = mask_head(acc[j], a.head_skip);
+                    acc[j][0] ^= a.state_ptr ? gf2_mulmod(*a.state_ptr, a.xinv_h) : a.state_fold;
+                }
             }
         }
         p += kTileVecs;
@@ -165,11 +172,14 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     constexpr int U = kUnroll;
     // First batch of the main loop is issued BEFORE the tables are staged, so
     // HBM latency and the table fill overlap.
-    u32x4 cur[U];
+    u32x4 cur[U][kVpl];
     const bool batched = USE_Y && ntiles >= U;
     if (batched) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < kVpl; ++j)
+                cur[u][j] = load_tile(srd, voff, soff + u * kTileBytes + j * kThreads * 16);
         soff += U * kTileBytes;
         ntiles -= U;
     }
@@ -200,32 +210,57 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     if (USE_Y) {
         if (batched) {
             while (ntiles >= U) {
-                u32x4 nxt[U];
+                u32x4 nxt[U][kVpl];
 #pragma unroll
-                for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j)
+                        nxt[u][j] = load_tile(srd, voff, soff + u * kTileBytes + j * kThreads * 16);
                 soff += U * kTileBytes;
                 ntiles -= U;
 #pragma unroll
-                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j) cur[u][j] = nxt[u][j];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
         }
         while (ntiles > 0) {
-            u32x4 w = load_tile(srd, voff, soff);
+#pragma unroll
+            for (int j = 0; j < kVpl; ++j) {
+                const u32x4 w = load_tile(srd, voff, soff + j * kThreads * 16);
+                horner_step(acc[j], w, ldsY, lane32);
+            }
             soff += kTileBytes;
             --ntiles;
-            horner_step(acc, w, ldsY, lane32);
         }
     }
 
-    // Lane residue over its four words, then its place in the tile, then XOR
-    // over the workgroup.
+    // Lane residue: each of its vectors folded over its four words with the
+    // x^32 table, earlier vectors carried forward by x^(128*kThreads) (uniform
+    // constant, rows C1); then the lane's place in the tile; then XOR over the
+    // workgroup.
     uint32_t r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+    for (int j = 0; j < kVpl; ++j) {
+        if (j > 0) {
+            uint32_t prod = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) prod ^= a.tabs->C1[i] & (0u - ((r >> (31 - i)) & 1u));
+            r = prod;
+        }
+        uint32_t rj = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rj = mul_x32(rj ^ acc[j][c], ldsX);
+        r ^= rj;
+    }
 #if defined(SIFT_ABLATE_MULMOD)  // timing-only build (tools/): wrong results by design
     r ^= kb[0] ^ kb[31];
 #else
