@@ -174,6 +174,14 @@ int sift_crc32_batch_device(int device, uint32_t state, uint32_t xor_out, const 
 int sift_read_chunks_device(int device, const void *d_base, const uint64_t *offsets,
                             const uint64_t *avail, uint32_t n, uint32_t *d_status,
                             uint32_t *d_data_len, void *stream);
+/* Chunk::write's CRC step (container.rs:75) on n serialized chunks whose
+ * length | type | data are already laid out in device memory with a 4-byte slot
+ * behind the data: computes each CRC over type | data and stores it big-endian
+ * into the slot.  avail[i] = bytes of chunk i's slot (>= 12 + its length);
+ * d_status[i] = SIFT_OK or SIFT_ERR_WRITE (slot too small). */
+int sift_write_chunk_crcs_device(int device, void *d_base, const uint64_t *offsets,
+                                 const uint64_t *avail, uint32_t n, uint32_t *d_status,
+                                 void *stream);
 int sift_read_documents_device(int device, const void *d_base, const uint64_t *offsets,
                                const uint64_t *avail, uint32_t n, uint32_t *d_status,
                                uint32_t *d_amrg_len, void *stream);

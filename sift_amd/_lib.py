@@ -36,7 +36,7 @@ EXPORTS = (
     "sift_profile_begin", "sift_profile_end", "sift_tune", "sift_crc32_workspace_bytes", "sift_crc32_compute_device",
     "sift_crc32_compute_device_sync", "sift_crc32_compute_host",
     "sift_digest_new", "sift_digest_update", "sift_digest_update_device",
-    "sift_digest_finalize", "sift_crc32_concat", "sift_chunk_crc_device", "sift_crc32_batch_device", "sift_read_chunks_device", "sift_read_documents_device",
+    "sift_digest_finalize", "sift_crc32_concat", "sift_chunk_crc_device", "sift_crc32_batch_device", "sift_read_chunks_device", "sift_read_documents_device", "sift_write_chunk_crcs_device",
     "sift_write_header", "sift_read_header", "sift_write_chunk", "sift_read_chunk",
     "sift_expect_type",
 )
@@ -100,6 +100,8 @@ def _load() -> C.CDLL:
     L.sift_read_chunks_device.argtypes = [i32, vp, vp, vp, u32, vp, vp, vp]
     L.sift_read_documents_device.restype = i32
     L.sift_read_documents_device.argtypes = [i32, vp, vp, vp, u32, vp, vp, vp]
+    L.sift_write_chunk_crcs_device.restype = i32
+    L.sift_write_chunk_crcs_device.argtypes = [i32, vp, vp, vp, u32, vp, vp]
     L.sift_write_header.restype = i64
     L.sift_write_header.argtypes = [vp, C.c_size_t]
     L.sift_read_header.restype = i64

@@ -133,3 +133,20 @@ def read_chunks_device(base: torch.Tensor, offsets, avail=None):
     end of `base`).  Returns (status, data_len) int32 device tensors; status is
     0 or the reference's error as in include/sift_amd.h.  Asynchronous."""
     return _batch(lib.sift_read_chunks_device, base, offsets, avail)
+
+
+def write_chunk_crcs_device(base: torch.Tensor, offsets, avail=None) -> torch.Tensor:
+    """Chunk::write's CRC step (container.rs:75) for n chunks serialized in place
+    in `base` (length | type | data | 4-byte slot): fills every slot with the
+    big-endian CRC of type | data.  Returns the int32 status tensor."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    av = (np.uint64(base.numel()) - off) if avail is None else np.ascontiguousarray(avail, dtype=np.uint64)
+    if off.size and int((off + av).max()) > base.numel():
+        raise ValueError("a window reaches past the end of base")
+    dev = base.device.index
+    status = torch.empty(off.size, dtype=torch.int32, device=base.device)
+    st = lib.sift_write_chunk_crcs_device(dev, base.data_ptr(), off.ctypes.data, av.ctypes.data, off.size,
+                                          status.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if st != _lib.OK:
+        raise _lib.SiftError(st)
+    return status

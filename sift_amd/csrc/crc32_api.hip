@@ -621,6 +621,13 @@ int sift_read_chunks_device(int device, const void* d_base, const uint64_t* offs
                      static_cast<hipStream_t>(stream));
 }
 
+int sift_write_chunk_crcs_device(int device, void* d_base, const uint64_t* offsets,
+                                 const uint64_t* avail, uint32_t n, uint32_t* d_status,
+                                 void* stream) {
+    return run_batch(device, d_base, offsets, avail, n, 0, 0, 3, d_status, nullptr,
+                     static_cast<hipStream_t>(stream));
+}
+
 int sift_read_documents_device(int device, const void* d_base, const uint64_t* offsets,
                                const uint64_t* avail, uint32_t n, uint32_t* d_status,
                                uint32_t* d_amrg_len, void* stream) {

@@ -121,6 +121,7 @@ struct BatchArgs {
     uint32_t verify;      // 0: out[i] = compute(state, buffer i) ^ xor_out
                           // 1: out[i] = status of Chunk::read on item i (SIFT_OK / SIFT_ERR_*)
                           // 2: out[i] = status of read_document's framing on file i
+                          // 3: store the CRC field of serialized chunk i (Chunk::write), out[i] = status
     uint32_t chunk_limit; // verify: container.rs:49 size cap
     uint32_t* out;
     uint32_t* data_len;   // verify, optional: data length of each chunk that parsed

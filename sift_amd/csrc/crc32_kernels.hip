@@ -526,6 +526,29 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             if (lane == 0) b.out[i] = r ^ b.xor_out;
             continue;
         }
+        if (b.verify == 3) {
+            // Chunk::write's last step x n (container.rs:75): the serialized chunk at
+            // ptr already holds length | type | data; compute the CRC over type | data
+            // and store it big-endian behind the data.  it.len = bytes of the slot.
+            uint32_t status = 0, dlen = 0;
+            if (it.len < 12u) {
+                status = 2;  // Error::Write: no room
+            } else {
+                dlen = be32(ptr);
+                if (it.len < 12ull + (uint64_t)dlen) status = 2;
+            }
+            if (status == 0) {
+                const uint32_t crc =
+                    wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
+                if (lane < 4u)
+                    const_cast<uint8_t*>(ptr)[8ull + dlen + lane] = (uint8_t)(crc >> (24u - 8u * lane));
+            }
+            if (lane == 0) {
+                b.out[i] = status;
+                if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
+            }
+            continue;
+        }
         if (b.verify == 1) {
             // Chunk::read x n
             uint32_t dlen = 0;

@@ -141,3 +141,34 @@ def test_read_documents_device(gpu, oracle):
     got = list(zip(status.cpu().tolist(), alen.cpu().tolist()))
     assert got == want
     assert {w[0] for w in want} == {0, 1, 5}
+
+
+def test_write_chunk_crcs_device(gpu, oracle):
+    # Chunk::write x n in place: lay out length | type | data | zeroed slot, let the GPU
+    # fill the CRC slots, compare every byte with the oracle's Chunk::write.
+    import struct as st
+    from sift_amd import container
+    rng = np.random.default_rng(13)
+    blob, want, offs, avail = bytearray(), bytearray(), [], []
+    for i, n in enumerate([0, 1, 5, 19, 20, 21, 1000, 65536, 1_500_000] + [int(x) for x in rng.integers(0, 4000, 300)]):
+        t = b"AMRG" if i % 2 else b"SEND"
+        d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        pad = bytes(int(rng.integers(0, 9)))
+        blob += pad
+        want += pad
+        offs.append(len(blob))
+        avail.append(12 + n)
+        blob += st.pack(">I", n) + t + d + b"\0\0\0\0"
+        want += oracle.write_chunk(t, d)
+    d = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+    status = container.write_chunk_crcs_device(d, offs, avail)
+    assert set(status.cpu().tolist()) == {0}
+    assert bytes(d.cpu().numpy()) == bytes(want)
+    # and what was written reads back clean
+    s2, dl = container.read_chunks_device(d, offs, avail)
+    assert set(s2.cpu().tolist()) == {0}
+    # a slot that is too small is Error::Write and leaves the bytes alone
+    avail[3] -= 1
+    d2 = torch.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint8).copy()).cuda()
+    s3 = container.write_chunk_crcs_device(d2, offs, avail).cpu().tolist()
+    assert s3[3] == 2 and s3[:3] == [0, 0, 0]
