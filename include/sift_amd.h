@@ -13,7 +13,7 @@
  * Conventions
  *  - plain C: pointers, sizes, integer status codes; no C++ or torch types.
  *  - every input byte is read and reduced on the GPU.  The host computes only
- *    length-dependent constants (x^(8n) mod P).  There is no CPU fallback:
+ *    geometry-dependent constants (a dozen GF(2) multiplies).  There is no CPU fallback:
  *    without a HIP device every compute call returns SIFT_ERR_NO_DEVICE.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - "state" is the running CRC register exactly as the reference keeps it in
@@ -107,10 +107,11 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_stat
 int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf, uint64_t len,
                                    uint32_t *out, void *stream);
 
-/* Host-resident input: stages `buf` to the device in pipelined pieces (copy
- * of piece i+1 overlaps the kernel of piece i), reduces it there, returns the
- * new state through `*out`.  This is the signature the reference's
- * compute(crc, buf) maps to one-to-one. */
+/* Host-resident input, reduced on the GPU; returns the new state through
+ * `*out`.  Pinned memory (hipHostMalloc / hipHostRegister) is read by the
+ * kernel in place over PCIe; pageable memory is staged in pipelined pieces
+ * (copy of piece i+1 overlaps the kernel of piece i).  This is the signature
+ * the reference's compute(crc, buf) maps to one-to-one. */
 int sift_crc32_compute_host(int device, uint32_t state, const void *buf, uint64_t len,
                             uint32_t *out);
 
