@@ -147,9 +147,11 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  * The data-parallel form of the two functions above, for callers that hold
  * many independent buffers / serialized chunks in HBM (bulk load of many
  * files).  One wave per buffer; buffers over 1 MiB in crc mode take the
- * whole-chip path one by one.  `offsets` / `lens` are HOST arrays of n
- * entries (byte offset from `d_base`, byte length); results go to device
- * memory, asynchronously on `stream`.
+ * whole-chip path one by one.  `offsets` / `lens` are arrays of n entries
+ * (byte offset from `d_base`, byte length), both in host memory or both in
+ * device memory; device arrays are used in place (nothing is copied, and every
+ * buffer is then reduced by one wave whatever its length).  Results go to
+ * device memory, asynchronously on `stream`.
  *
  * sift_crc32_batch_device:  d_out[i] = compute(state, buffer i) ^ xor_out
  *                           (crc.rs:28-34 applied n times; state = 0xFFFFFFFF,

@@ -104,15 +104,24 @@ def read_chunk(reader, pos: int = 0, device: int | None = None):
     return Chunk(bytes(t), a[start:start + ln.value].tobytes()), pos + int(n)
 
 
+def _windows(base: torch.Tensor, offsets, avail):
+    """Descriptor pointers for host sequences or int64 device tensors."""
+    from .crc import _descriptors
+    if avail is None:
+        if isinstance(offsets, torch.Tensor) and offsets.is_cuda:
+            avail = base.numel() - offsets
+        else:
+            off = np.ascontiguousarray(offsets, dtype=np.uint64)
+            avail = np.uint64(base.numel()) - off
+    return _descriptors(base, offsets, avail)
+
+
 def _batch(fn, base: torch.Tensor, offsets, avail):
-    off = np.ascontiguousarray(offsets, dtype=np.uint64)
-    av = (np.uint64(base.numel()) - off) if avail is None else np.ascontiguousarray(avail, dtype=np.uint64)
-    if off.size and int((off + av).max()) > base.numel():
-        raise ValueError("a window reaches past the end of base")
+    po, pa, n, keep = _windows(base, offsets, avail)
     dev = base.device.index
-    status = torch.empty(off.size, dtype=torch.int32, device=base.device)
-    dlen = torch.empty(off.size, dtype=torch.int32, device=base.device)
-    st = fn(dev, base.data_ptr(), off.ctypes.data, av.ctypes.data, off.size, status.data_ptr(),
+    status = torch.empty(n, dtype=torch.int32, device=base.device)
+    dlen = torch.empty(n, dtype=torch.int32, device=base.device)
+    st = fn(dev, base.data_ptr(), po, pa, n, status.data_ptr(),
             dlen.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if st != _lib.OK:
         raise _lib.SiftError(st)
@@ -139,13 +148,10 @@ def write_chunk_crcs_device(base: torch.Tensor, offsets, avail=None) -> torch.Te
     """Chunk::write's CRC step (container.rs:75) for n chunks serialized in place
     in `base` (length | type | data | 4-byte slot): fills every slot with the
     big-endian CRC of type | data.  Returns the int32 status tensor."""
-    off = np.ascontiguousarray(offsets, dtype=np.uint64)
-    av = (np.uint64(base.numel()) - off) if avail is None else np.ascontiguousarray(avail, dtype=np.uint64)
-    if off.size and int((off + av).max()) > base.numel():
-        raise ValueError("a window reaches past the end of base")
+    po, pa, n, keep = _windows(base, offsets, avail)
     dev = base.device.index
-    status = torch.empty(off.size, dtype=torch.int32, device=base.device)
-    st = lib.sift_write_chunk_crcs_device(dev, base.data_ptr(), off.ctypes.data, av.ctypes.data, off.size,
+    status = torch.empty(n, dtype=torch.int32, device=base.device)
+    st = lib.sift_write_chunk_crcs_device(dev, base.data_ptr(), po, pa, n,
                                           status.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if st != _lib.OK:
         raise _lib.SiftError(st)

@@ -101,21 +101,35 @@ def concat(state_a: int, state_b0: int, len_b: int) -> int:
     return int(lib.sift_crc32_concat(state_a & 0xFFFFFFFF, state_b0 & 0xFFFFFFFF, len_b))
 
 
-def compute_batch(crc: int, base: torch.Tensor, offsets, lens, xor_out: int = 0,
-                  out: torch.Tensor | None = None) -> torch.Tensor:
-    """compute(crc, buffer i) ^ xor_out for n buffers inside the device tensor
-    `base` (crc.rs:28-34 applied n times, one wave per buffer).  `offsets` and
-    `lens` are host sequences.  Returns an int32 device tensor (bit pattern of
-    the u32 results); asynchronous on the current stream."""
+def _descriptors(base: torch.Tensor, offsets, lens):
+    """(offsets_ptr, lens_ptr, n, keepalive) for host sequences or device int64 tensors."""
+    if isinstance(offsets, torch.Tensor) and offsets.is_cuda:
+        if not (isinstance(lens, torch.Tensor) and lens.is_cuda):
+            raise TypeError("offsets and lens must both be host sequences or both device tensors")
+        if offsets.dtype != torch.int64 or lens.dtype != torch.int64:
+            raise TypeError("device offsets / lens must be int64")
+        off, ln = offsets.contiguous(), lens.contiguous()
+        assert off.shape == ln.shape and off.ndim == 1
+        return off.data_ptr(), ln.data_ptr(), off.numel(), (off, ln)
     off = np.ascontiguousarray(offsets, dtype=np.uint64)
     ln = np.ascontiguousarray(lens, dtype=np.uint64)
     assert off.shape == ln.shape and off.ndim == 1
     if off.size and int((off + ln).max()) > base.numel():
         raise ValueError("a buffer reaches past the end of base")
+    return off.ctypes.data, ln.ctypes.data, off.size, (off, ln)
+
+
+def compute_batch(crc: int, base: torch.Tensor, offsets, lens, xor_out: int = 0,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """compute(crc, buffer i) ^ xor_out for n buffers inside the device tensor
+    `base` (crc.rs:28-34 applied n times, one wave per buffer).  `offsets` and
+    `lens` are host sequences, or int64 device tensors (used in place; the caller
+    vouches that every buffer lies inside `base`).  Returns an int32 device
+    tensor (bit pattern of the u32 results); asynchronous on the current stream."""
+    po, pl, n, keep = _descriptors(base, offsets, lens)
     dev = base.device.index
     if out is None:
-        out = torch.empty(off.size, dtype=torch.int32, device=base.device)
+        out = torch.empty(n, dtype=torch.int32, device=base.device)
     check(lib.sift_crc32_batch_device(dev, crc & 0xFFFFFFFF, xor_out & 0xFFFFFFFF, base.data_ptr(),
-                                      off.ctypes.data, ln.ctypes.data, off.size, out.data_ptr(),
-                                      _stream_ptr(dev)))
+                                      po, pl, n, out.data_ptr(), _stream_ptr(dev)))
     return out

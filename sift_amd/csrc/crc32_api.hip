@@ -567,19 +567,37 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    std::vector<BatchItem> items(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        items[i].offset = offsets[i];
-        // crc mode: long buffers are skipped by the wave kernel (len 0 -> trivial) and redone below
-        items[i].len = (!verify && lens[i] > kBatchWaveMax) ? 0 : lens[i];
+    // Descriptors already in device memory are used in place (no copy, and no
+    // host knowledge of the lengths: every buffer then goes to one wave).
+    auto on_device = [](const void* p) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
+            return true;
+        (void)hipGetLastError();  // a plain host pointer is not an error here
+        return false;
+    };
+    const bool dev_desc = on_device(offsets) && on_device(lens);
+    uint64_t* d_desc = nullptr;
+    const uint64_t* k_offsets = offsets;
+    const uint64_t* k_lens = lens;
+    if (!dev_desc) {
+        std::vector<uint64_t> desc(2 * (size_t)n);
+        for (uint32_t i = 0; i < n; ++i) {
+            desc[i] = offsets[i];
+            // crc mode: long buffers are skipped by the wave kernel (len 0 -> trivial) and redone below
+            desc[(size_t)n + i] = (!verify && lens[i] > kBatchWaveMax) ? 0 : lens[i];
+        }
+        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), sizeof(uint64_t) * 2 * n, stream));
+        // pageable source: the runtime stages it before returning, so `desc` may die with this frame
+        SIFT_HIP(hipMemcpyAsync(d_desc, desc.data(), sizeof(uint64_t) * 2 * n, hipMemcpyHostToDevice,
+                                stream));
+        k_offsets = d_desc;
+        k_lens = d_desc + n;
     }
-    BatchItem* d_items = nullptr;
-    SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_items), sizeof(BatchItem) * n, stream));
-    // pageable source: the runtime stages it before returning, so `items` may die with this frame
-    SIFT_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(BatchItem) * n, hipMemcpyHostToDevice, stream));
     BatchArgs b;
     b.base = static_cast<const uint8_t*>(d_base);
-    b.items = d_items;
+    b.offsets = k_offsets;
+    b.lens = k_lens;
     b.n = n;
     b.state = state;
     b.xor_out = xor_out;
@@ -593,8 +611,8 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
                                          (uint64_t)c->groups_max);
     launch_batch(b, groups, stream);
     SIFT_HIP(hipGetLastError());
-    SIFT_HIP(hipFreeAsync(d_items, stream));
-    if (!verify) {
+    if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, stream));
+    if (!verify && !dev_desc) {
         for (uint32_t i = 0; i < n; ++i) {
             if (lens[i] <= kBatchWaveMax) continue;
             rc = launch_compute(c, state, nullptr, static_cast<const uint8_t*>(d_base) + offsets[i],

@@ -103,18 +103,14 @@ struct CombineMats {
     uint32_t z[kTreeLevels][32];
 };
 
-// Batch kernel (one wave per buffer).  kBatchItem describes one buffer:
-// `offset` bytes from `base`; `len` bytes long.  In verify mode the item is a
-// serialized chunk (container.rs:47-66): `len` is the number of bytes
-// available from `offset`, the chunk's own length comes from its header.
-struct BatchItem {
-    uint64_t offset;
-    uint64_t len;
-};
-
+// Batch kernel (one wave per buffer).  Buffer i is `lens[i]` bytes at
+// `base + offsets[i]`.  In the verify / write modes the item is a serialized
+// chunk or file (container.rs:47-77): `lens[i]` is the number of bytes
+// available from its offset, its own length comes from its header.
 struct BatchArgs {
     const uint8_t* base;
-    const BatchItem* items;
+    const uint64_t* offsets;  // device arrays of n entries
+    const uint64_t* lens;
     uint32_t n;
     uint32_t state;       // starting register for every buffer (crc mode)
     uint32_t xor_out;     // crc mode: XORed into each result

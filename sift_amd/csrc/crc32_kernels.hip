@@ -519,7 +519,9 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     const uint32_t wave = blockIdx.x * (uint32_t)kWaves + (tid >> 6);
     const uint32_t nwaves = gridDim.x * (uint32_t)kWaves;
     for (uint32_t i = wave; i < b.n; i += nwaves) {
-        const BatchItem it = b.items[i];
+        struct {
+            uint64_t offset, len;
+        } const it = {b.offsets[i], b.lens[i]};
         const uint8_t* ptr = b.base + it.offset;
         if (!b.verify) {
             const uint32_t r = wave_crc(ptr, it.len, b.state, ldsY, ldsX, lane, lane32, aw);
