@@ -260,3 +260,29 @@ def test_two_threads_two_streams(gpu, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_random_differential(gpu):
+    # 400 random (offset, length, state) triples across every geometry the host
+    # picks (1..256 groups, 1..10 tiles per group, ragged first tiles, tails),
+    # against zlib.crc32 -- an implementation independent of both oracle and product.
+    rng = np.random.default_rng(0x51F7 + 99)
+    big = rng.integers(0, 256, size=(48 << 20) + 4096, dtype=np.uint8)
+    d = torch.from_numpy(big).cuda()
+    hb = big.tobytes()
+    M = 0xFFFFFFFF
+    for i in range(400):
+        kind = i % 4
+        if kind == 0:
+            n = int(rng.integers(32, 70000))
+        elif kind == 1:
+            n = int(rng.integers(70000, 5 << 20))
+        elif kind == 2:
+            n = int(rng.integers(1, 2600)) * 16384 + int(rng.integers(-40, 41))  # near tile multiples
+        else:
+            n = int(rng.integers(5 << 20, 44 << 20))
+        off = int(rng.integers(0, 4096))
+        state = int(rng.integers(0, 1 << 32))
+        want = zlib.crc32(hb[off:off + n], state ^ M) ^ M
+        got = gpu.compute(state, d[off:off + n])
+        assert got == want, (i, off, n, hex(state), hex(got), hex(want))
