@@ -191,8 +191,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     if (USE_Y) {
 #endif
 #pragma unroll 16
-        for (int i = 0; i < kYWords / kThreads; ++i)
-            ldsY[i * kThreads + tid] = a.tabs->Y[i * (kThreads / kRepl) + (tid >> kReplLog2)];
+        for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = a.tabs->Y[i >> kReplLog2];
     }
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = a.tabs->X[i];
     // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its
@@ -510,8 +509,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     const uint32_t lane = tid & 63u;
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
 #pragma unroll 16
-    for (int i = 0; i < kYWords / kThreads; ++i)
-        ldsY[i * kThreads + tid] = b.tabs->Y1[i * (kThreads / kRepl) + (tid >> kReplLog2)];
+    for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kReplLog2];
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
     const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
     __syncthreads();
