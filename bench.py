@@ -8,9 +8,9 @@ defines the contingency workload measured here: compute(0xFFFFFFFF, buf)
 
 A step is one compute() over the whole buffer, resident in HBM before the
 timed region.  With N > 1 (one process per GPU) the logical buffer is N GiB,
-rank r owns range r, and a step additionally all-gathers one (state, length)
-pair per rank over RCCL and stitches them -- weak scaling, no data-path
-collective.
+rank r owns range r, and the job ends with one all-gather of every step's
+(state, length) pair per rank over RCCL and a stitch per step -- weak scaling,
+no data-path collective.
 
 Prints one JSON line (rank 0).  `roofline` is for the tile kernel, timed with
 HIP events on its own stream during the timed steps; `cpu_baseline` is the C
@@ -107,26 +107,19 @@ def main() -> None:
     ws = torch.zeros(sift_amd.workspace_bytes(), dtype=torch.uint8, device=dev)
     K, W = args.steps, args.warmup
     pairs = torch.zeros(max(K, 1), 2, dtype=torch.int64, device=dev)
-    gathered = torch.zeros(max(K, 1), 2 * world, dtype=torch.int64, device=dev)
     pairs[:, 1] = n
 
     def run(steps):
         """`steps` passes of the hot path plus the read-back and host stitch of
         every pass's result: the whole job, nothing cached between passes.
-        With N > 1 every pass has its own 16-byte-per-rank all-gather, issued
-        asynchronously so that pass i+1's reduction overlaps pass i's exchange;
-        all of them are waited for before the clock stops."""
-        works = []
+        With N > 1 the (state, length) pairs of all passes are exchanged in ONE
+        all-gather after the last pass (fewer, larger collectives: 16 bytes per
+        rank per pass), inside the timed region, and every pass is stitched."""
         for i in range(steps):
             sharded.local_state_async(0xFFFFFFFF, buf, rank, pairs[i], ws)
-            if world > 1:
-                works.append(dist.all_gather_into_tensor(gathered[i], pairs[i], async_op=True))
-        for w in works:
-            w.wait()
-        torch.cuda.synchronize()
         if world > 1:
-            return [sharded.stitch([(s & 0xFFFFFFFF, l) for s, l in row.view(world, 2).tolist()])
-                    for row in gathered[:steps].cpu()]
+            return sharded.exchange_and_stitch(pairs[:steps])
+        torch.cuda.synchronize()
         return [int(s) & 0xFFFFFFFF for s in pairs[:steps, 0].cpu().tolist()]
 
     def fence():
@@ -188,7 +181,7 @@ def main() -> None:
                 "bytes_per_gpu_per_step": n,
                 "preheat_ms": args.preheat_ms,
                 "result": f"0x{results[0]:08x}",
-                "parallelism": f"range-sharded x{world}, (state,len) all-gather" if world > 1
+                "parallelism": f"range-sharded x{world}, one (state,len) all-gather per job" if world > 1
                                else "single GPU",
             },
             "roofline": {

@@ -60,3 +60,17 @@ def sharded_compute(crc: int, local, group=None,
     dist.all_gather_into_tensor(gathered, pair, group=group)
     pairs = gathered.view(world, 2).cpu().tolist()
     return stitch([(s & 0xFFFFFFFF, l) for s, l in pairs])
+
+
+def exchange_and_stitch(pairs: torch.Tensor, group=None) -> list:
+    """`pairs` is this rank's [steps, 2] int64 tensor of (state, length) for
+    `steps` independent buffers, each split over the ranks in rank order.  One
+    all-gather moves all of them (16 bytes per rank per buffer); returns the
+    `steps` stitched registers, identical on every rank."""
+    world = dist.get_world_size(group)
+    steps = pairs.shape[0]
+    flat = torch.empty(world * steps * 2, dtype=torch.int64, device=pairs.device)
+    dist.all_gather_into_tensor(flat, pairs.reshape(-1).contiguous(), group=group)
+    g = flat.view(world, steps, 2).cpu().tolist()
+    return [stitch([(g[r][i][0] & 0xFFFFFFFF, g[r][i][1]) for r in range(world)])
+            for i in range(steps)]

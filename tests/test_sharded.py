@@ -36,6 +36,44 @@ def _worker(rank, world, port, cuts, seed, init_state, q):
         dist.destroy_process_group()
 
 
+def _worker_many(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle
+        from sift_amd import sharded
+        rng = np.random.default_rng(3)
+        steps = 5
+        fulls = [rng.integers(0, 256, size=int(n), dtype=np.uint8) for n in (10, 4000, 70001, 1, 33333)]
+        pairs = torch.zeros(steps, 2, dtype=torch.int64)
+        for i, full in enumerate(fulls):
+            cut = full.size // 3
+            part = full[:cut] if rank == 0 else full[cut:]
+            pairs[i, 0] = c_oracle.compute(0xFFFFFFFF if rank == 0 else 0, part)
+            pairs[i, 1] = part.size
+        got = sharded.exchange_and_stitch(pairs)
+        q.put((rank, got, [c_oracle.compute(0xFFFFFFFF, f) for f in fulls]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_many_buffers_one_all_gather():
+    # bench.py's N > 1 exchange: every step's pair in one all-gather, then a stitch per step
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_many, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, want in res:
+        assert got == want, rank
+
+
 @pytest.mark.parametrize("cuts,init_state", [
     ([0, 1000, 2500], 0xFFFFFFFF),
     ([0, 0, 77], 0xFFFFFFFF),          # empty first shard
