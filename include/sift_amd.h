@@ -146,8 +146,9 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
 /* ------------------------------------------------ many buffers at once -----
  * The data-parallel form of the two functions above, for callers that hold
  * many independent buffers / serialized chunks in HBM (bulk load of many
- * files).  One wave per buffer; buffers over 1 MiB in crc mode take the
- * whole-chip path one by one.  `offsets` / `lens` are arrays of n entries
+ * files).  One wave per buffer; in crc mode with host descriptors a buffer
+ * over 256 KiB is cut into 256 KiB pieces (one wave each, stitched by a second
+ * small kernel) and one of 64 MiB or more takes the whole-chip path.  `offsets` / `lens` are arrays of n entries
  * (byte offset from `d_base`, byte length), both in host memory or both in
  * device memory; device arrays are used in place (nothing is copied, and every
  * buffer is then reduced by one wave whatever its length).  Results go to

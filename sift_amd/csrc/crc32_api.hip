@@ -547,9 +547,29 @@ uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b) 
 
 namespace {
 
-// Buffers longer than this leave the one-wave-per-buffer kernel and take the
-// whole-chip path one by one.
-constexpr uint64_t kBatchWaveMax = 1ull << 20;
+// crc mode, lengths known on the host.  Three size classes:
+//   up to kPiece              one wave reduces the buffer
+//   kPiece .. kBatchChipMin   cut into pieces of kPiece bytes (the FIRST piece takes
+//                             the remainder and the starting register), one wave per
+//                             piece, then a Horner pass over the pieces' registers
+//                             with the one constant x^(8*kPiece) (crc32_stitch_kernel)
+//   kBatchChipMin and up      the whole-chip path, one launch per buffer
+constexpr uint64_t kPiece = 256ull << 10;
+constexpr uint64_t kBatchChipMin = 64ull << 20;
+
+const uint32_t* piece_rows() {
+    static const struct Rows {
+        uint32_t v[32];
+        Rows() {
+            uint32_t r = gf2_xpow(x2n(), 8ull * kPiece);
+            for (int k = 0; k < 32; ++k) {
+                v[k] = r;
+                r = gf2_mulx(r);
+            }
+        }
+    } rows;
+    return rows.v;
+}
 
 int run_batch(int device, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
               uint32_t n, uint32_t state, uint32_t xor_out, int verify, uint32_t* d_out,
@@ -557,6 +577,10 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     if (n == 0) return SIFT_OK;
     if (!offsets || !lens || !d_out || !d_base) {
         g_last_error = "NULL pointer";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    if (n >= 0x80000000u) {
+        g_last_error = "too many buffers in one batch";
         return SIFT_ERR_INVALID_ARG;
     }
     DeviceCtx* c = nullptr;
@@ -577,28 +601,10 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         return false;
     };
     const bool dev_desc = on_device(offsets) && on_device(lens);
-    uint64_t* d_desc = nullptr;
-    const uint64_t* k_offsets = offsets;
-    const uint64_t* k_lens = lens;
-    if (!dev_desc) {
-        std::vector<uint64_t> desc(2 * (size_t)n);
-        for (uint32_t i = 0; i < n; ++i) {
-            desc[i] = offsets[i];
-            // crc mode: long buffers are skipped by the wave kernel (len 0 -> trivial) and redone below
-            desc[(size_t)n + i] = (!verify && lens[i] > kBatchWaveMax) ? 0 : lens[i];
-        }
-        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), sizeof(uint64_t) * 2 * n, stream));
-        // pageable source: the runtime stages it before returning, so `desc` may die with this frame
-        SIFT_HIP(hipMemcpyAsync(d_desc, desc.data(), sizeof(uint64_t) * 2 * n, hipMemcpyHostToDevice,
-                                stream));
-        k_offsets = d_desc;
-        k_lens = d_desc + n;
-    }
+
     BatchArgs b;
+    std::memset(&b, 0, sizeof(b));
     b.base = static_cast<const uint8_t*>(d_base);
-    b.offsets = k_offsets;
-    b.lens = k_lens;
-    b.n = n;
     b.state = state;
     b.xor_out = xor_out;
     b.verify = (uint32_t)verify;
@@ -607,14 +613,109 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     b.data_len = d_data_len;
     b.tabs = c->d_tabs;
     const int waves_per_group = kThreads / 64;
-    int groups = (int)std::min<uint64_t>((n + waves_per_group - 1) / waves_per_group,
-                                         (uint64_t)c->groups_max);
-    launch_batch(b, groups, stream);
-    SIFT_HIP(hipGetLastError());
-    if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, stream));
-    if (!verify && !dev_desc) {
+    auto groups_for = [&](uint64_t items) {
+        return (int)std::min<uint64_t>((items + waves_per_group - 1) / waves_per_group,
+                                       (uint64_t)c->groups_max);
+    };
+
+    if (dev_desc) {
+        b.offsets = offsets;
+        b.lens = lens;
+        b.n = n;
+        launch_batch(b, groups_for(n), stream);
+        SIFT_HIP(hipGetLastError());
+        return SIFT_OK;
+    }
+
+    // Host descriptors.  Work items for the wave kernel: whole buffers and pieces.
+    const bool cut = !verify;  // only plain crc buffers are cut; a chunk's length is in its header
+    std::vector<uint64_t> w_off, w_len;
+    std::vector<uint32_t> w_state, w_dst, s_item, s_first, s_count;
+    w_off.reserve(n);
+    w_len.reserve(n);
+    uint32_t scratch_words = 0;
+    bool any_cut = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t len = lens[i];
+        if (cut && len >= kBatchChipMin) continue;  // whole-chip launch below
+        if (!cut || len <= kPiece) {
+            w_off.push_back(offsets[i]);
+            w_len.push_back(len);
+            w_state.push_back(state);
+            w_dst.push_back(i);
+            continue;
+        }
+        any_cut = true;
+        const uint32_t count = (uint32_t)((len + kPiece - 1) / kPiece);
+        const uint64_t first_len = len - (uint64_t)(count - 1) * kPiece;
+        s_item.push_back(i);
+        s_first.push_back(scratch_words);
+        s_count.push_back(count);
+        uint64_t off = offsets[i];
+        for (uint32_t j = 0; j < count; ++j) {
+            const uint64_t pl = j == 0 ? first_len : kPiece;
+            w_off.push_back(off);
+            w_len.push_back(pl);
+            w_state.push_back(j == 0 ? state : 0u);
+            w_dst.push_back(0x80000000u | scratch_words++);
+            off += pl;
+        }
+    }
+    const size_t m = w_off.size();
+    if (m >= 0x80000000ull) {
+        g_last_error = "too many pieces in one batch";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    if (m) {
+        // One device allocation: offsets | lens | (states | dst | scratch | item | first | count)
+        const size_t ns = s_item.size();
+        const size_t u64s = 2 * m;
+        const size_t u32s = any_cut ? 2 * m + scratch_words + 3 * ns : 0;
+        uint64_t* d_desc = nullptr;
+        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), 8 * u64s + 4 * u32s, stream));
+        std::vector<uint64_t> h64(u64s);
+        std::copy(w_off.begin(), w_off.end(), h64.begin());
+        std::copy(w_len.begin(), w_len.end(), h64.begin() + m);
+        // pageable sources: the runtime stages them before returning, so the vectors may die here
+        SIFT_HIP(hipMemcpyAsync(d_desc, h64.data(), 8 * u64s, hipMemcpyHostToDevice, stream));
+        b.offsets = d_desc;
+        b.lens = d_desc + m;
+        b.n = (uint32_t)m;
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(d_desc + u64s);
+        if (any_cut) {
+            std::vector<uint32_t> h32;
+            h32.reserve(u32s);
+            h32.insert(h32.end(), w_state.begin(), w_state.end());
+            h32.insert(h32.end(), w_dst.begin(), w_dst.end());
+            h32.resize(2 * m + scratch_words, 0u);
+            h32.insert(h32.end(), s_item.begin(), s_item.end());
+            h32.insert(h32.end(), s_first.begin(), s_first.end());
+            h32.insert(h32.end(), s_count.begin(), s_count.end());
+            SIFT_HIP(hipMemcpyAsync(d32, h32.data(), 4 * u32s, hipMemcpyHostToDevice, stream));
+            b.states = d32;
+            b.dst = d32 + m;
+            b.scratch = d32 + 2 * m;
+        }
+        launch_batch(b, groups_for(m), stream);
+        SIFT_HIP(hipGetLastError());
+        if (any_cut) {
+            StitchArgs st;
+            st.scratch = b.scratch;
+            st.item = d32 + 2 * m + scratch_words;
+            st.first = st.item + ns;
+            st.count = st.first + ns;
+            st.n = (uint32_t)ns;
+            st.xor_out = xor_out;
+            st.out = d_out;
+            std::memcpy(st.piece_rows, piece_rows(), sizeof(st.piece_rows));
+            launch_stitch(st, (int)std::min<size_t>((ns + 3) / 4, 1024), stream);
+            SIFT_HIP(hipGetLastError());
+        }
+        SIFT_HIP(hipFreeAsync(d_desc, stream));
+    }
+    if (cut) {
         for (uint32_t i = 0; i < n; ++i) {
-            if (lens[i] <= kBatchWaveMax) continue;
+            if (lens[i] < kBatchChipMin) continue;
             rc = launch_compute(c, state, nullptr, static_cast<const uint8_t*>(d_base) + offsets[i],
                                 lens[i], xor_out, d_out + i, ring_slot(c), stream);
             if (rc != SIFT_OK) return rc;

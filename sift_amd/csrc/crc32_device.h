@@ -122,8 +122,27 @@ struct BatchArgs {
     uint32_t* out;
     uint32_t* data_len;   // verify, optional: data length of each chunk that parsed
     const DeviceTables* tabs;
+    // crc mode with long buffers cut into pieces (host descriptors only), else null:
+    const uint32_t* states;  // starting register of item i
+    const uint32_t* dst;     // where item i's result goes: index into out, or
+                             // 0x80000000 | index into scratch (raw, for the stitch kernel)
+    uint32_t* scratch;
 };
 
+// Stitch kernel: buffer s of the cut ones is out[item[s]]; its pieces' raw
+// registers are scratch[first[s] .. first[s] + count[s]).
+struct StitchArgs {
+    const uint32_t* scratch;
+    const uint32_t* item;
+    const uint32_t* first;
+    const uint32_t* count;
+    uint32_t n;
+    uint32_t xor_out;
+    uint32_t* out;
+    uint32_t piece_rows[32];  // x^(8 * piece bytes) * x^k
+};
+
+void launch_stitch(const StitchArgs& a, int groups, void* stream);
 void launch_batch(const BatchArgs& b, int groups, void* stream);
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,

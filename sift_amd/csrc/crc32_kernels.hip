@@ -522,8 +522,18 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         } const it = {b.offsets[i], b.lens[i]};
         const uint8_t* ptr = b.base + it.offset;
         if (!b.verify) {
-            const uint32_t r = wave_crc(ptr, it.len, b.state, ldsY, ldsX, lane, lane32, aw);
-            if (lane == 0) b.out[i] = r ^ b.xor_out;
+            // Plain buffers, or pieces of longer buffers (b.states / b.dst set by
+            // the host): a piece starts from its own register and its raw result
+            // goes to the scratch array for crc32_stitch_kernel.
+            const uint32_t start = b.states ? b.states[i] : b.state;
+            const uint32_t r = wave_crc(ptr, it.len, start, ldsY, ldsX, lane, lane32, aw);
+            if (lane == 0) {
+                const uint32_t d = b.dst ? b.dst[i] : i;
+                if (d & 0x80000000u)
+                    b.scratch[d & 0x7FFFFFFFu] = r;
+                else
+                    b.out[d] = r ^ b.xor_out;
+            }
             continue;
         }
         if (b.verify == 3) {
@@ -591,6 +601,32 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             if (b.data_len) b.data_len[i] = status == 0 ? amrg_len : 0u;
         }
     }
+}
+
+// Buffers of a batch that were cut into pieces (all but the first kPiece
+// bytes long): Horner over the pieces' raw registers with x^(8*kPiece), one
+// wave per buffer, the constant multiply done by 32 lanes together.
+__global__ __launch_bounds__(256) void crc32_stitch_kernel(StitchArgs a) {
+    const uint32_t lane = threadIdx.x & 63u, k = threadIdx.x & 31u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t row = a.piece_rows[k];  // x^(8*kPiece) * x^k
+    for (uint32_t s = wave; s < a.n; s += nwaves) {
+        const uint32_t first = a.first[s], count = a.count[s];
+        uint32_t r = a.scratch[first];
+        for (uint32_t j = 1; j < count; ++j) {
+            uint32_t t = ((r >> (31u - k)) & 1u) ? row : 0u;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
+            r = t ^ a.scratch[first + j];
+        }
+        if (lane == 0) a.out[a.item[s]] = r ^ a.xor_out;
+    }
+}
+
+void launch_stitch(const StitchArgs& a, int groups, void* stream) {
+    hipLaunchKernelGGL(crc32_stitch_kernel, dim3(groups), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
 }
 
 void launch_batch(const BatchArgs& b, int groups, void* stream) {

@@ -198,3 +198,21 @@ def test_device_resident_descriptors(gpu, oracle):
     dc = torch.from_numpy(np.frombuffer(bytes(ser), dtype=np.uint8).copy()).cuda()
     st, dl = container.read_chunks_device(dc, torch.tensor(coffs, dtype=torch.int64, device="cuda"))
     assert st.cpu().tolist() == [0, 0, 5, 0] and dl.cpu().tolist() == [0, 7, 0, 40000]
+
+
+def test_batch_size_classes(gpu):
+    # one wave / cut into 256 KiB pieces and stitched / whole-chip launch, in one batch
+    import zlib
+    rng = np.random.default_rng(23)
+    blob = rng.integers(0, 256, size=(80 << 20) + 64, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    lens = [100, 262144, 262145, 524288, 524289, (5 << 20) + 3, (63 << 20) + 1, 64 << 20, (70 << 20) + 9,
+            0, 31, 32, 300000, (1 << 20) - 1]
+    offs = [int(rng.integers(0, blob.size - n + 1)) for n in lens]
+    M = 0xFFFFFFFF
+    for state, xo in ((M, M), (0x1234ABCD, 0)):
+        got = gpu.compute_batch(state, d, offs, lens, xor_out=xo).cpu().numpy().view(np.uint32)
+        for i, (o, n) in enumerate(zip(offs, lens)):
+            want = (zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo
+            assert int(got[i]) == want, (i, o, n, hex(int(got[i])), hex(want))

@@ -19,7 +19,7 @@ TOTAL = 1 << 30
 blob = torch.randint(0, 256, (TOTAL,), dtype=torch.uint8, device="cuda")
 host = blob[: 64 << 20].cpu().numpy()
 rows = []
-for size in (64, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20):
+for size in (64, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20):
     n = min(TOTAL // size, 1 << 20)
     offs = np.arange(n, dtype=np.uint64) * np.uint64(size)
     lens = np.full(n, size, dtype=np.uint64)
