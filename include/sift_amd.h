@@ -163,7 +163,11 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  *                           SIFT_ERR_READ_INVALID_CHUNK_SIZE or
  *                           SIFT_ERR_READ_CRC_MISMATCH, raised in the reference's
  *                           order; d_data_len[i] (optional, may be NULL) = data
- *                           length of chunk i if it parsed, else 0.
+ *                           length of chunk i if it parsed, else 0.  A chunk's
+ *                           length is only known on the device, so each chunk is
+ *                           checked by one wave whatever its size: meant for many
+ *                           small chunks; check a single large chunk with
+ *                           sift_chunk_crc_device (whole chip) instead.
  * sift_read_documents_device: the framing of read_document (document.rs:62-77)
  *                           on n whole save files: read_header, read_chunk +
  *                           expect_type(AMRG), read_chunk + expect_type(SEND).
