@@ -56,6 +56,45 @@ __global__ __launch_bounds__(1024) void read_runs(const u32x4* base, size_t tile
     if (r == 0x12345678u) out[blockIdx.x] = r;  // keeps the loads alive
 }
 
+// read_runs<2> plus synthetic work per loaded vector: V rounds of 4 VALU ops per
+// word and L conflict-free LDS lookups per word (same table layout as the CRC
+// kernel).  Separates "the loop has arithmetic" from "the loop reads LDS".
+template <int V, int L>
+__global__ __launch_bounds__(1024) void read_runs_work(const u32x4* base, size_t tiles_per_group,
+                                                       uint32_t* out) {
+    __shared__ uint32_t tab[32768];
+    for (int i = threadIdx.x; i < 32768; i += 1024) tab[i] = i * 2654435761u;
+    __syncthreads();
+    const uint32_t lane32 = threadIdx.x & 31u;
+    const u32x4* p = base + (size_t)blockIdx.x * tiles_per_group * 1024 + threadIdx.x;
+    u32x4 acc = {1, 2, 3, 4};
+    u32x4 cur[2], nxt[2];
+    cur[0] = __builtin_nontemporal_load(p);
+    cur[1] = __builtin_nontemporal_load(p + 1024);
+    for (size_t t = 2; t + 2 <= tiles_per_group; t += 2) {
+        nxt[0] = __builtin_nontemporal_load(p + t * 1024);
+        nxt[1] = __builtin_nontemporal_load(p + (t + 1) * 1024);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t a = acc[c];
+#pragma unroll
+                for (int v = 0; v < V; ++v) a = ((a >> 3) ^ (a << 5)) + (a & 0x55aa55aau);
+                uint32_t x = 0;
+#pragma unroll
+                for (int l = 0; l < L; ++l) x ^= tab[l * 8192 + (((a >> (8 * l)) & 0xffu) << 5) + lane32];
+                acc[c] = (a ^ x) ^ cur[u][c];
+            }
+        }
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+    }
+    acc ^= cur[0] ^ cur[1];
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;
+}
+
 // Round-robin tiles: workgroup g reads tiles g, g+G, g+2G, ... (the whole chip
 // sweeps the buffer front to back together).
 template <int U>
@@ -245,6 +284,32 @@ int main(int argc, char** argv) {
             const double bytes = 256.0 * tp[v] * 16384.0;
             std::printf("stream spacing: runs of %zu tiles  median %7.2f us  %7.1f GB/s\n", tp[v],
                         tt[5] * 1e3, bytes / (tt[5] * 1e-3) / 1e9);
+        }
+    }
+    // Where does the CRC loop's ~3 % streaming loss come from?  Pure read with
+    // synthetic VALU-only, LDS-only and combined work of the CRC loop's size.
+    {
+        const char* wn[5] = {"read + nothing", "read + 12 VALU/word (V=3)", "read + 4 LDS lookups/word",
+                             "read + 2 LDS lookups/word", "read + 3 VALU rounds + 4 lookups"};
+        for (int v = 0; v < 5; ++v) {
+            std::vector<float> tt;
+            for (int r = 0; r < 12; ++r) {
+                float t;
+                CK(hipEventRecord(e0));
+                switch (v) {
+                    case 0: read_runs_work<0, 0><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 1: read_runs_work<3, 0><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 2: read_runs_work<0, 4><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 3: read_runs_work<0, 2><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                    case 4: read_runs_work<3, 4><<<256, 1024>>>((const u32x4*)buf, tpg, out); break;
+                }
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&t, e0, e1));
+                if (r >= 2) tt.push_back(t);
+            }
+            std::sort(tt.begin(), tt.end());
+            std::printf("synthetic work: %-34s median %7.2f us\n", wn[v], tt[5] * 1e3);
         }
     }
     // Fixed cost of a call: same grid, 2 tiles per group (table fill + tail +
