@@ -244,7 +244,7 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     const int64_t tpg = (ntile + groups - 1) / groups;
     groups = (ntile + tpg - 1) / tpg;
     f.groups = (int32_t)groups;
-    if ((uint64_t)tpg * kTileBytes >= (1ull << 31)) {
+    if ((uint64_t)tpg * kTileBytes >= (1ull << 31) - (1ull << 24)) {
         // a workgroup addresses its run through a signed 32-bit buffer offset
         g_last_error = "buffer too large for this device's workgroup count";
         return SIFT_ERR_INVALID_ARG;
