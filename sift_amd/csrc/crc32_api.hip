@@ -670,7 +670,10 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         // One device allocation: offsets | lens | (states | dst | scratch | item | first | count)
         const size_t ns = s_item.size();
         const size_t u64s = 2 * m;
-        const size_t u32s = any_cut ? 2 * m + scratch_words + 3 * ns : 0;
+        // Work item k is buffer w_dst[k], not buffer k, as soon as a buffer was cut
+        // or skipped (whole-chip launch below): the kernel then needs the map.
+        const bool need_map = any_cut || m != n;
+        const size_t u32s = need_map ? 2 * m + scratch_words + 3 * ns : 0;
         uint64_t* d_desc = nullptr;
         SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), 8 * u64s + 4 * u32s, stream));
         std::vector<uint64_t> h64(u64s);
@@ -682,7 +685,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         b.lens = d_desc + m;
         b.n = (uint32_t)m;
         uint32_t* d32 = reinterpret_cast<uint32_t*>(d_desc + u64s);
-        if (any_cut) {
+        if (need_map) {
             std::vector<uint32_t> h32;
             h32.reserve(u32s);
             h32.insert(h32.end(), w_state.begin(), w_state.end());

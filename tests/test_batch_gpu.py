@@ -216,3 +216,26 @@ def test_batch_size_classes(gpu):
         for i, (o, n) in enumerate(zip(offs, lens)):
             want = (zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo
             assert int(got[i]) == want, (i, o, n, hex(int(got[i])), hex(want))
+
+
+def test_batch_whole_chip_buffers_keep_their_slots(gpu):
+    # buffers of 64 MiB and more leave the wave kernel's work list; the small ones
+    # behind them must still land in their own result slots (no buffer in the
+    # 256 KiB .. 64 MiB class here, so nothing is cut)
+    import zlib
+    rng = np.random.default_rng(29)
+    blob = rng.integers(0, 256, size=(140 << 20) + 64, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    M = 0xFFFFFFFF
+    for lens in ([64 << 20, 100], [100, 64 << 20, 31, (70 << 20) + 5, 5000], [(65 << 20) + 1]):
+        offs, pos = [], 0
+        for n in lens:
+            offs.append(pos + 3)
+            pos += n + 3
+        for state, xo in ((M, M), (0x1234ABCD, 0)):
+            out = torch.full((len(lens),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+            got = gpu.compute_batch(state, d, offs, lens, xor_out=xo, out=out).cpu().numpy().view(np.uint32)
+            for i, (o, n) in enumerate(zip(offs, lens)):
+                want = (zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo
+                assert int(got[i]) == want, (lens, i, hex(int(got[i])), hex(want))
