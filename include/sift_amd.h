@@ -103,7 +103,29 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_stat
                               const void *d_buf, uint64_t len, uint32_t *d_out,
                               void *workspace, void *stream);
 
-/* Same, then waits and returns the new state through `*out` (host). */
+/* The same computation for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART
+ * IN THE REFERENCE (it never leaves the CPU).  Like sift_crc32_compute_device with
+ * workspace = NULL, except that the workspace is a 4.5 KiB array in the
+ * library's own static device memory (one copy per GPU, held until the process
+ * ends) instead of a slot of the allocated ring, and that the call itself makes
+ * no hipMalloc / hipFree or any other allocating call.  Requirements:
+ *  - sift_init(device) has returned SIFT_OK earlier (set-up allocates the
+ *    constant tables; this call does not, and returns SIFT_ERR_INVALID_ARG if the
+ *    device was never initialised);
+ *  - len <= SIFT_STATIC_MAX_LEN, else SIFT_ERR_INVALID_ARG (the scratch holds one
+ *    residue per workgroup whatever the length, so the limit is an addressing
+ *    one, not a capacity one);
+ *  - every call on one GPU shares that GPU's array: two calls that overlap in
+ *    time on one GPU (different streams or threads) race and both results are
+ *    undefined.  Calls queued on ONE stream are fine.  The accumulator and the
+ *    arrival counter are cleared on the stream at the start of every call. */
+#define SIFT_STATIC_MAX_LEN (1ull << 38) /* 256 GiB */
+int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t *d_state_in,
+                                     const void *d_buf, uint64_t len, uint32_t *d_out,
+                                     void *stream);
+
+/* Same as sift_crc32_compute_device, then waits and returns the new state through `*out` (host). */
 int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf, uint64_t len,
                                    uint32_t *out, void *stream);
 

@@ -29,12 +29,13 @@ TUNE_SINGLE_LAUNCH = 1
 HEADER_LEN = 9
 CHUNK_SIZE_LIMIT = 1024 * 1024 * 1024
 CRC_INIT = 0xFFFFFFFF
+STATIC_MAX_LEN = 1 << 38
 
 # every symbol include/sift_amd.h declares; tests check the .so exports them all
 EXPORTS = (
     "sift_strerror", "sift_last_error", "sift_init", "sift_shutdown",
     "sift_profile_begin", "sift_profile_end", "sift_tune", "sift_crc32_workspace_bytes", "sift_crc32_compute_device",
-    "sift_crc32_compute_device_sync", "sift_crc32_compute_host",
+    "sift_crc32_compute_device_static", "sift_crc32_compute_device_sync", "sift_crc32_compute_host",
     "sift_digest_new", "sift_digest_update", "sift_digest_update_device",
     "sift_digest_finalize", "sift_crc32_concat", "sift_chunk_crc_device", "sift_crc32_batch_device", "sift_read_chunks_device", "sift_read_documents_device", "sift_write_chunk_crcs_device",
     "sift_write_header", "sift_read_header", "sift_write_chunk", "sift_read_chunk",
@@ -78,6 +79,8 @@ def _load() -> C.CDLL:
     L.sift_crc32_workspace_bytes.argtypes = []
     L.sift_crc32_compute_device.restype = i32
     L.sift_crc32_compute_device.argtypes = [i32, u32, vp, vp, u64, vp, vp, vp]
+    L.sift_crc32_compute_device_static.restype = i32
+    L.sift_crc32_compute_device_static.argtypes = [i32, u32, vp, vp, u64, vp, vp]
     L.sift_crc32_compute_device_sync.restype = i32
     L.sift_crc32_compute_device_sync.argtypes = [i32, u32, vp, u64, C.POINTER(u32), vp]
     L.sift_crc32_compute_host.restype = i32

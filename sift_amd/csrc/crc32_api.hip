@@ -45,6 +45,15 @@ constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32
 constexpr size_t kSlotWords = kMaxGroups + 96;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
 
+// Scratch of sift_crc32_compute_device_static, the entry point that allocates
+// nothing: one workspace slot in the code object's own device memory.  Each GPU
+// that loads the library holds its own copy at its own address, until the process
+// ends.  In host code the NAME below is only a handle for hipGetSymbolAddress
+// (HIP_SYMBOL); the memory is reached through DeviceCtx::static_scratch, the
+// per-device address that get_ctx() asks the runtime for.
+constexpr size_t kStaticScratchWords = (kSlotWords + 63) / 64 * 64;  // whole 256-B lines
+static __device__ __align__(256) uint32_t scratch[kStaticScratchWords];
+
 const X2nTable& x2n() {
     static const X2nTable t = make_x2n_table();
     return t;
@@ -55,6 +64,7 @@ struct DeviceCtx {
     int groups_max = 0;  // workgroups per launch = CUs (one 132 KiB-LDS workgroup per CU)
     DeviceTables* d_tabs = nullptr;
     uint32_t* d_ring = nullptr;  // kRingSlots * kSlotWords
+    uint32_t* static_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
     unsigned ring_next = 0;
     // host-input staging (sift_crc32_compute_host)
     uint8_t* d_stage[2] = {nullptr, nullptr};
@@ -143,6 +153,8 @@ int get_ctx(int device, DeviceCtx** out) {
     SIFT_HIP(hipMalloc(&c->d_ring, kRingSlots * kSlotWords * sizeof(uint32_t)));
     SIFT_HIP(hipMemset(c->d_ring, 0, kRingSlots * kSlotWords * sizeof(uint32_t)));
     SIFT_HIP(hipMalloc(&c->d_state, 256));
+    // This device's address of the static scratch array (this device is current).
+    SIFT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&c->static_scratch), HIP_SYMBOL(scratch)));
     SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), 64 * 64, hipHostMallocDefault));
     SIFT_HIP(hipSetDevice(prev));
     g_ctx[device] = c;
@@ -429,6 +441,43 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t* d_stat
     uint32_t* ws = workspace ? static_cast<uint32_t*>(workspace) : ring_slot(c);
     return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws,
                           static_cast<hipStream_t>(stream));
+}
+
+int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t* d_state_in,
+                                     const void* d_buf, uint64_t len, uint32_t* d_out,
+                                     void* stream) {
+    // Allocates nothing: the context (tables, this device's scratch address) must
+    // exist already, so sift_init(device) has to come first.
+    DeviceCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        if (device >= 0 && device < (int)g_ctx.size()) c = g_ctx[device];
+    }
+    if (!c || !c->static_scratch) {
+        g_last_error = "sift_crc32_compute_device_static: call sift_init(device) first "
+                       "(this entry point allocates nothing, so it cannot set the device up)";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    if (len > SIFT_STATIC_MAX_LEN) {
+        g_last_error = "sift_crc32_compute_device_static: len exceeds SIFT_STATIC_MAX_LEN (256 GiB)";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* ws = c->static_scratch;
+    // The array keeps whatever the last call on this GPU left.  The kernels leave
+    // the accumulator and the arrival counter at zero when they finish, but a call
+    // that was aborted does not: clear both (two 128-B lines) on the stream first.
+    // By a kernel, not hipMemsetAsync: captured into a HIP graph, the memset node gave
+    // wrong results from the second replay on (ROCm 7.2, gfx950; the kernel form and
+    // the eager memset are both fine).
+    launch_clear(ws + kExchangeWord, s);
+    SIFT_HIP(hipGetLastError());
+    return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws, s);
 }
 
 int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf, uint64_t len,

@@ -142,6 +142,7 @@ struct StitchArgs {
     uint32_t piece_rows[32];  // x^(8 * piece bytes) * x^k
 };
 
+void launch_clear(uint32_t* words, void* stream);
 void launch_stitch(const StitchArgs& a, int groups, void* stream);
 void launch_batch(const BatchArgs& b, int groups, void* stream);
 

@@ -624,6 +624,13 @@ __global__ __launch_bounds__(256) void crc32_stitch_kernel(StitchArgs a) {
     }
 }
 
+// Zeroes 64 words (two 128-B lines: accumulator, arrival counter) of a workspace.
+__global__ __launch_bounds__(64) void crc32_clear_kernel(uint32_t* words) { words[threadIdx.x] = 0u; }
+
+void launch_clear(uint32_t* words, void* stream) {
+    hipLaunchKernelGGL(crc32_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), words);
+}
+
 void launch_stitch(const StitchArgs& a, int groups, void* stream) {
     hipLaunchKernelGGL(crc32_stitch_kernel, dim3(groups), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);

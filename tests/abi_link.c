@@ -11,6 +11,7 @@ int main(void) {
         (void *)sift_strerror, (void *)sift_last_error, (void *)sift_init, (void *)sift_shutdown,
         (void *)sift_crc32_workspace_bytes, (void *)sift_profile_begin, (void *)sift_profile_end,
         (void *)sift_tune, (void *)sift_crc32_compute_device, (void *)sift_crc32_compute_device_sync,
+        (void *)sift_crc32_compute_device_static,
         (void *)sift_crc32_compute_host, (void *)sift_digest_new, (void *)sift_digest_update,
         (void *)sift_digest_update_device, (void *)sift_digest_finalize, (void *)sift_crc32_concat,
         (void *)sift_chunk_crc_device, (void *)sift_crc32_batch_device, (void *)sift_read_chunks_device,
