@@ -80,9 +80,14 @@ int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
 
 /* Measurement knobs, process-wide.  No reference counterpart. */
 enum {
-    SIFT_TUNE_SINGLE_LAUNCH = 1 /* 1 (default): the last workgroup to arrive combines the
-                                   residues inside the tile kernel; 0: a second, combine
-                                   kernel does (A/B measurement only, same results) */
+    SIFT_TUNE_SINGLE_LAUNCH = 1, /* 1 (default): the last workgroup to arrive combines the
+                                    residues inside the tile kernel; 0: a second, combine
+                                    kernel does (A/B measurement only, same results) */
+    SIFT_TUNE_BATCH_CUT = 2,     /* 1 (default): the batch entry points cut long items on the
+                                    device; 0: one wave per item whatever its length */
+    SIFT_TUNE_BATCH_WAVE_MAX = 3,/* bytes of CRC span one wave keeps before the item is cut;
+                                    0 (default) = 256 KiB for n >= 4096 items, else 32 KiB */
+    SIFT_TUNE_BATCH_PIECE_LOG2 = 4 /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
 };
 int sift_tune(int key, int value);
 

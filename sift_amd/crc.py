@@ -114,7 +114,8 @@ def _descriptors(base: torch.Tensor, offsets, lens):
     off = np.ascontiguousarray(offsets, dtype=np.uint64)
     ln = np.ascontiguousarray(lens, dtype=np.uint64)
     assert off.shape == ln.shape and off.ndim == 1
-    if off.size and int((off + ln).max()) > base.numel():
+    numel = np.uint64(base.numel())
+    if off.size and bool(((ln > numel) | (off > numel - np.minimum(ln, numel))).any()):  # no u64 wrap
         raise ValueError("a buffer reaches past the end of base")
     return off.ctypes.data, ln.ctypes.data, off.size, (off, ln)
 

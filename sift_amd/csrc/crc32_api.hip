@@ -26,6 +26,10 @@ thread_local std::string g_last_error;
 // second launch.  sift_tune(SIFT_TUNE_SINGLE_LAUNCH, 0) selects the two-launch
 // form for A/B measurement.
 bool g_single_launch = true;
+// Tuning knobs of the batch entry points (sift_tune).
+int g_batch_cut = 1;          // 0: every item stays on one wave (round-1 behaviour, A/B only)
+int g_batch_wave_max = 0;     // bytes a single wave keeps; 0 = chosen from n (run_batch)
+int g_batch_piece_log2 = kPieceMinLog2;
 
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -111,6 +115,14 @@ void build_tables(DeviceTables* t) {
         t->C1[i] = c1;
         c1 = gf2_mulx(c1);
     }
+    for (int sq = 0; sq < 32; ++sq) {
+        uint32_t r = x2n().v[sq];
+        for (int k = 0; k < 32; ++k) {
+            t->X2[sq][k] = r;
+            r = gf2_mulx(r);
+        }
+    }
+    for (uint64_t h = 0; h < 16; ++h) t->XinvH[h] = gf2_xpow(x2n(), 0xFFFFFFFFull - 8ull * h);
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {
@@ -419,10 +431,23 @@ int sift_tune(int key, int value) {
         case SIFT_TUNE_SINGLE_LAUNCH:
             g_single_launch = value != 0;
             return SIFT_OK;
+        case SIFT_TUNE_BATCH_CUT:
+            g_batch_cut = value != 0;
+            return SIFT_OK;
+        case SIFT_TUNE_BATCH_WAVE_MAX:
+            if (value != 0 && value < 4096) break;
+            g_batch_wave_max = value;
+            return SIFT_OK;
+        case SIFT_TUNE_BATCH_PIECE_LOG2:
+            if (value < 14 || value > 24) break;  // whole 16 KiB tiles
+            g_batch_piece_log2 = value;
+            return SIFT_OK;
         default:
             g_last_error = "unknown tuning key";
             return SIFT_ERR_INVALID_ARG;
     }
+    g_last_error = "tuning value out of range";
+    return SIFT_ERR_INVALID_ARG;
 }
 
 size_t sift_crc32_workspace_bytes(void) { return kSlotWords * sizeof(uint32_t); }
@@ -596,30 +621,33 @@ uint32_t sift_crc32_concat(uint32_t state_a, uint32_t state_b0, uint64_t len_b) 
 
 namespace {
 
-// crc mode, lengths known on the host.  Three size classes:
-//   up to kPiece              one wave reduces the buffer
-//   kPiece .. kBatchChipMin   cut into pieces of kPiece bytes (the FIRST piece takes
-//                             the remainder and the starting register), one wave per
-//                             piece, then a Horner pass over the pieces' registers
-//                             with the one constant x^(8*kPiece) (crc32_stitch_kernel)
-//   kBatchChipMin and up      the whole-chip path, one launch per buffer
-constexpr uint64_t kPiece = 256ull << 10;
-constexpr uint64_t kBatchChipMin = 64ull << 20;
-
-const uint32_t* piece_rows() {
-    static const struct Rows {
-        uint32_t v[32];
-        Rows() {
-            uint32_t r = gf2_xpow(x2n(), 8ull * kPiece);
-            for (int k = 0; k < 32; ++k) {
-                v[k] = r;
-                r = gf2_mulx(r);
-            }
+// Where a descriptor array lives.
+enum class Where { Host, Pinned, Device };
+Where where_is(const void* p, const void** dev_ptr) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+        if (attr.type == hipMemoryTypeDevice) {
+            *dev_ptr = p;
+            return Where::Device;
         }
-    } rows;
-    return rows.v;
+        if (attr.type == hipMemoryTypeHost && attr.devicePointer) {
+            *dev_ptr = attr.devicePointer;
+            return Where::Pinned;
+        }
+    }
+    (void)hipGetLastError();  // a plain host pointer is not an error here
+    return Where::Host;
 }
 
+// The batch entry points.  Three launches on `stream`:
+//   1. crc32_batch_kernel       one wave per item; an item whose CRC span is long
+//                               is filed (record + pieces) instead of walked
+//   2. crc32_pieces_kernel      one workgroup per filed piece (tile algorithm)
+//   3. crc32_cut_finish_kernel  one wave per filed record: XOR of its residues,
+//                               tail bytes, verdict
+// The lengths that decide what is long are read on the device (from `lens`, or
+// from each chunk's header in the verify modes), so it makes no difference
+// whether the descriptors came from the host or were already in HBM.
 int run_batch(int device, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
               uint32_t n, uint32_t state, uint32_t xor_out, int verify, uint32_t* d_out,
               uint32_t* d_data_len, hipStream_t stream) {
@@ -640,20 +668,20 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    // Descriptors already in device memory are used in place (no copy, and no
-    // host knowledge of the lengths: every buffer then goes to one wave).
-    auto on_device = [](const void* p) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice)
-            return true;
-        (void)hipGetLastError();  // a plain host pointer is not an error here
-        return false;
-    };
-    const bool dev_desc = on_device(offsets) && on_device(lens);
+    // Descriptors: device arrays and pinned host arrays (device-addressable) are
+    // used in place; pageable host arrays are copied, straight from the caller's
+    // memory, into a stream-ordered allocation.
+    const void *dv_off = nullptr, *dv_len = nullptr;
+    const Where w_off = where_is(offsets, &dv_off), w_len = where_is(lens, &dv_len);
+    if ((w_off == Where::Device) != (w_len == Where::Device)) {
+        g_last_error = "offsets and lens must both be host arrays or both be device arrays";
+        return SIFT_ERR_INVALID_ARG;
+    }
 
     BatchArgs b;
     std::memset(&b, 0, sizeof(b));
     b.base = static_cast<const uint8_t*>(d_base);
+    b.n = n;
     b.state = state;
     b.xor_out = xor_out;
     b.verify = (uint32_t)verify;
@@ -661,118 +689,70 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     b.out = d_out;
     b.data_len = d_data_len;
     b.tabs = c->d_tabs;
-    const int waves_per_group = kThreads / 64;
-    auto groups_for = [&](uint64_t items) {
-        return (int)std::min<uint64_t>((items + waves_per_group - 1) / waves_per_group,
-                                       (uint64_t)c->groups_max);
-    };
 
-    if (dev_desc) {
-        b.offsets = offsets;
-        b.lens = lens;
-        b.n = n;
-        launch_batch(b, groups_for(n), stream);
-        SIFT_HIP(hipGetLastError());
-        return SIFT_OK;
-    }
-
-    // Host descriptors.  Work items for the wave kernel: whole buffers and pieces.
-    const bool cut = !verify;  // only plain crc buffers are cut; a chunk's length is in its header
-    std::vector<uint64_t> w_off, w_len;
-    std::vector<uint32_t> w_state, w_dst, s_item, s_first, s_count;
-    w_off.reserve(n);
-    w_len.reserve(n);
-    uint32_t scratch_words = 0;
-    bool any_cut = false;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t len = lens[i];
-        if (cut && len >= kBatchChipMin) continue;  // whole-chip launch below
-        if (!cut || len <= kPiece) {
-            w_off.push_back(offsets[i]);
-            w_len.push_back(len);
-            w_state.push_back(state);
-            w_dst.push_back(i);
-            continue;
-        }
-        any_cut = true;
-        const uint32_t count = (uint32_t)((len + kPiece - 1) / kPiece);
-        const uint64_t first_len = len - (uint64_t)(count - 1) * kPiece;
-        s_item.push_back(i);
-        s_first.push_back(scratch_words);
-        s_count.push_back(count);
-        uint64_t off = offsets[i];
-        for (uint32_t j = 0; j < count; ++j) {
-            const uint64_t pl = j == 0 ? first_len : kPiece;
-            w_off.push_back(off);
-            w_len.push_back(pl);
-            w_state.push_back(j == 0 ? state : 0u);
-            w_dst.push_back(0x80000000u | scratch_words++);
-            off += pl;
+    // Scratch of the cutting pass.  The host cannot see the lengths, so the
+    // capacities come from what fits in the allocation `d_base` points into:
+    // filed spans are longer than wave_max, so non-overlapping items give at most
+    // extent / wave_max records, and a record of body B has at most B / piece + 1
+    // pieces.  Items that overlap can exceed this; a span that finds the arrays
+    // full is walked by its own wave instead (same bits, slower).
+    const bool cut = g_batch_cut != 0;
+    const uint32_t wave_max = g_batch_wave_max > 0 ? (uint32_t)g_batch_wave_max
+                                                   : (n >= 4096u ? (256u << 10) : (32u << 10));
+    uint64_t extent = 1ull << 30;
+    {
+        hipDeviceptr_t abase = nullptr;
+        size_t asize = 0;
+        if (hipMemGetAddressRange(&abase, &asize, const_cast<void*>(d_base)) == hipSuccess && asize) {
+            extent = reinterpret_cast<uint64_t>(abase) + asize - reinterpret_cast<uint64_t>(d_base);
+        } else {
+            (void)hipGetLastError();
         }
     }
-    const size_t m = w_off.size();
-    if (m >= 0x80000000ull) {
-        g_last_error = "too many pieces in one batch";
-        return SIFT_ERR_INVALID_ARG;
+    const uint64_t cap_recs = std::min<uint64_t>(n, extent / wave_max + 1);
+    const uint64_t cap_pieces = std::min<uint64_t>((extent >> g_batch_piece_log2) + cap_recs + 1, 0x7FFFFFFFull);
+    const size_t copy_bytes = (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
+    const size_t cut_bytes = cut ? 256 + sizeof(CutRecord) * cap_recs + 8 * cap_pieces : 0;
+    uint8_t* d_tmp = nullptr;
+    if (copy_bytes + cut_bytes)
+        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tmp), cut_bytes + copy_bytes, stream));
+    uint8_t* d_desc = d_tmp + cut_bytes;
+    if (w_off == Where::Host) {
+        // pageable source: the runtime has consumed it when the call returns
+        SIFT_HIP(hipMemcpyAsync(d_desc, offsets, 8ull * n, hipMemcpyHostToDevice, stream));
+        dv_off = d_desc;
+        d_desc += 8ull * n;
     }
-    if (m) {
-        // One device allocation: offsets | lens | (states | dst | scratch | item | first | count)
-        const size_t ns = s_item.size();
-        const size_t u64s = 2 * m;
-        // Work item k is buffer w_dst[k], not buffer k, as soon as a buffer was cut
-        // or skipped (whole-chip launch below): the kernel then needs the map.
-        const bool need_map = any_cut || m != n;
-        const size_t u32s = need_map ? 2 * m + scratch_words + 3 * ns : 0;
-        uint64_t* d_desc = nullptr;
-        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), 8 * u64s + 4 * u32s, stream));
-        std::vector<uint64_t> h64(u64s);
-        std::copy(w_off.begin(), w_off.end(), h64.begin());
-        std::copy(w_len.begin(), w_len.end(), h64.begin() + m);
-        // pageable sources: the runtime stages them before returning, so the vectors may die here
-        SIFT_HIP(hipMemcpyAsync(d_desc, h64.data(), 8 * u64s, hipMemcpyHostToDevice, stream));
-        b.offsets = d_desc;
-        b.lens = d_desc + m;
-        b.n = (uint32_t)m;
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(d_desc + u64s);
-        if (need_map) {
-            std::vector<uint32_t> h32;
-            h32.reserve(u32s);
-            h32.insert(h32.end(), w_state.begin(), w_state.end());
-            h32.insert(h32.end(), w_dst.begin(), w_dst.end());
-            h32.resize(2 * m + scratch_words, 0u);
-            h32.insert(h32.end(), s_item.begin(), s_item.end());
-            h32.insert(h32.end(), s_first.begin(), s_first.end());
-            h32.insert(h32.end(), s_count.begin(), s_count.end());
-            SIFT_HIP(hipMemcpyAsync(d32, h32.data(), 4 * u32s, hipMemcpyHostToDevice, stream));
-            b.states = d32;
-            b.dst = d32 + m;
-            b.scratch = d32 + 2 * m;
-        }
-        launch_batch(b, groups_for(m), stream);
-        SIFT_HIP(hipGetLastError());
-        if (any_cut) {
-            StitchArgs st;
-            st.scratch = b.scratch;
-            st.item = d32 + 2 * m + scratch_words;
-            st.first = st.item + ns;
-            st.count = st.first + ns;
-            st.n = (uint32_t)ns;
-            st.xor_out = xor_out;
-            st.out = d_out;
-            std::memcpy(st.piece_rows, piece_rows(), sizeof(st.piece_rows));
-            launch_stitch(st, (int)std::min<size_t>((ns + 3) / 4, 1024), stream);
-            SIFT_HIP(hipGetLastError());
-        }
-        SIFT_HIP(hipFreeAsync(d_desc, stream));
+    if (w_len == Where::Host) {
+        SIFT_HIP(hipMemcpyAsync(d_desc, lens, 8ull * n, hipMemcpyHostToDevice, stream));
+        dv_len = d_desc;
     }
+    b.offsets = static_cast<const uint64_t*>(dv_off);
+    b.lens = static_cast<const uint64_t*>(dv_len);
     if (cut) {
-        for (uint32_t i = 0; i < n; ++i) {
-            if (lens[i] < kBatchChipMin) continue;
-            rc = launch_compute(c, state, nullptr, static_cast<const uint8_t*>(d_base) + offsets[i],
-                                lens[i], xor_out, d_out + i, ring_slot(c), stream);
-            if (rc != SIFT_OK) return rc;
-        }
+        b.cut.cursor = reinterpret_cast<unsigned long long*>(d_tmp);
+        b.cut.recs = reinterpret_cast<CutRecord*>(d_tmp + 256);
+        b.cut.piece_rec = reinterpret_cast<uint32_t*>(d_tmp + 256 + sizeof(CutRecord) * cap_recs);
+        b.cut.piece_res = b.cut.piece_rec + cap_pieces;
+        b.cut.cap_recs = (uint32_t)cap_recs;
+        b.cut.cap_pieces = (uint32_t)cap_pieces;
+        b.cut.wave_max = wave_max;
+        b.cut.piece_min_log2 = (uint32_t)g_batch_piece_log2;
+        launch_clear(reinterpret_cast<uint32_t*>(d_tmp), stream);  // cursor = 0
+        SIFT_HIP(hipGetLastError());
     }
+    const int waves_per_group = kThreads / 64;
+    const int groups = (int)std::min<uint64_t>(((uint64_t)n + waves_per_group - 1) / waves_per_group,
+                                               (uint64_t)c->groups_max);
+    launch_batch(b, groups, stream);
+    SIFT_HIP(hipGetLastError());
+    if (cut) {
+        launch_pieces(b, c->groups_max, stream);
+        SIFT_HIP(hipGetLastError());
+        launch_cut_finish(b, (int)std::min<uint64_t>((cap_recs + 3) / 4, 1024), stream);
+        SIFT_HIP(hipGetLastError());
+    }
+    if (d_tmp) SIFT_HIP(hipFreeAsync(d_tmp, stream));
     return SIFT_OK;
 }
 

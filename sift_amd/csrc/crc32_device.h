@@ -55,6 +55,8 @@ struct DeviceTables {
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
     uint32_t C1[32];         // C1[i] = x^(128*kThreads) * x^i: from one of a lane's vectors to its next
+    uint32_t X2[32][32];     // X2[s][k] = x^(2^s) * x^k: row k of the matrix of x^(2^s) (piece weights)
+    uint32_t XinvH[16];      // XinvH[h] = x^(-8h): folds a starting register into a vector with h pad bytes
 };
 
 // Arguments of the tile kernel.
@@ -103,6 +105,40 @@ struct CombineMats {
     uint32_t z[kTreeLevels][32];
 };
 
+// Device-side cutting of long items (batch kernels).  A long CRC span is not
+// walked by the wave that finds it: that wave files a record and the span is cut
+// into np pieces of (kPieceMinBytes << level) bytes, each reduced by a whole
+// workgroup (crc32_pieces_kernel, the tile kernel's algorithm), and a last small
+// kernel XORs the weighted piece residues and finishes the item.  Cuts are at
+// absolute 16-byte boundaries counted back from the end of the span's body, so
+// only piece 0 has a ragged head and only the finisher sees the < 16 tail bytes.
+constexpr int kPieceMinLog2 = 16;            // 64 KiB: four 16 KiB tiles
+constexpr uint32_t kMaxPiecesPerItem = 1024; // level is raised until np fits (up to kMaxLevel)
+constexpr uint32_t kMaxLevel = 14;           // pieces of at most 1 GiB (32-bit buffer offsets)
+
+struct CutRecord {
+    uint64_t span_off;    // first byte of the CRC span, from BatchArgs::base
+    uint64_t span_len;
+    uint32_t item;        // index into out / data_len
+    uint32_t piece_base;  // its pieces are piece_base .. piece_base + np
+    uint32_t np;
+    uint32_t level;
+    uint32_t cont;        // status the item gets if the span's CRC matches (verify modes)
+    uint32_t dlen;        // verify modes: data length of the chunk
+    uint32_t pad[2];
+};
+static_assert(sizeof(CutRecord) == 48, "CutRecord layout");
+
+struct CutArgs {
+    unsigned long long* cursor;  // hi 32 bits: records filed, lo 32 bits: pieces reserved; null = never cut
+    CutRecord* recs;
+    uint32_t* piece_rec;         // piece -> record slot
+    uint32_t* piece_res;         // piece -> residue, weighted to the end of its span's body
+    uint32_t cap_recs, cap_pieces;
+    uint32_t wave_max;           // spans of up to this many bytes stay on the wave that found them
+    uint32_t piece_min_log2;     // smallest piece, log2 bytes (kPieceMinLog2 unless tuned)
+};
+
 // Batch kernel (one wave per buffer).  Buffer i is `lens[i]` bytes at
 // `base + offsets[i]`.  In the verify / write modes the item is a serialized
 // chunk or file (container.rs:47-77): `lens[i]` is the number of bytes
@@ -122,30 +158,13 @@ struct BatchArgs {
     uint32_t* out;
     uint32_t* data_len;   // verify, optional: data length of each chunk that parsed
     const DeviceTables* tabs;
-    // crc mode with long buffers cut into pieces (host descriptors only), else null:
-    const uint32_t* states;  // starting register of item i
-    const uint32_t* dst;     // where item i's result goes: index into out, or
-                             // 0x80000000 | index into scratch (raw, for the stitch kernel)
-    uint32_t* scratch;
+    CutArgs cut;
 };
 
-// Stitch kernel: buffer s of the cut ones is out[item[s]]; its pieces' raw
-// registers are scratch[first[s] .. first[s] + count[s]).
-struct StitchArgs {
-    const uint32_t* scratch;
-    const uint32_t* item;
-    const uint32_t* first;
-    const uint32_t* count;
-    uint32_t n;
-    uint32_t xor_out;
-    uint32_t* out;
-    uint32_t piece_rows[32];  // x^(8 * piece bytes) * x^k
-};
-
-void launch_clear(uint32_t* words, void* stream);
-void launch_stitch(const StitchArgs& a, int groups, void* stream);
 void launch_batch(const BatchArgs& b, int groups, void* stream);
-
+void launch_pieces(const BatchArgs& b, int groups, void* stream);
+void launch_cut_finish(const BatchArgs& b, int groups, void* stream);
+void launch_clear(uint32_t* words, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);
 void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,

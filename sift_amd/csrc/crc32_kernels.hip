@@ -479,20 +479,98 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
 }
 
+// x <- x * c, c given as the 32 rows c * x^k of its matrix: lane k of each
+// half-wave holds row k and contributes it when bit 31-k of x is set; a 5-step
+// butterfly sums the rows.  Every lane of the wave returns the product.
+__device__ __forceinline__ uint32_t mul_rows(uint32_t x, uint32_t row, uint32_t row32) {
+    uint32_t t = ((x >> (31u - row32)) & 1u) ? row : 0u;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
+    return t;
+}
+
+// A wave that meets a long CRC span files it for the piece kernel instead of
+// walking it.  Wave-uniform.  Returns false (nothing changed) when cutting is off,
+// the span is short, or the record / piece arrays are full: the caller then
+// walks the span itself, which is slow for a long span but gives the same bits.
+__device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, const uint8_t* ptr,
+                                          uint64_t len, uint32_t cont, uint32_t dlen,
+                                          uint32_t lane) {
+    const CutArgs& c = b.cut;
+    if (!c.cursor || len <= (uint64_t)c.wave_max) return false;
+    const uint64_t A = reinterpret_cast<uint64_t>(ptr);
+    const uint64_t body = ((A + len) & ~15ull) - (A & ~15ull);  // whole vectors, > 0 here
+    uint32_t level = 0;
+    while (level < kMaxLevel - (c.piece_min_log2 - (uint32_t)kPieceMinLog2) &&
+           (body >> (c.piece_min_log2 + level)) >= (uint64_t)kMaxPiecesPerItem)
+        ++level;
+    const uint32_t plog = c.piece_min_log2 + level;
+    const uint64_t np64 = (body + (1ull << plog) - 1) >> plog;
+    if (np64 > 0x40000000ull) return false;
+    const uint32_t np = (uint32_t)np64;
+    // Reserve one record and np pieces together: one 64-bit word, records in the
+    // high half.  Compare-and-swap, so a reservation that does not fit changes
+    // nothing and the counts never pass the capacities.
+    unsigned long long got = ~0ull;
+    if (lane == 0) {
+        unsigned long long cur = __hip_atomic_load(c.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const uint32_t nrec = (uint32_t)(cur >> 32), npc = (uint32_t)cur;
+            if (nrec >= c.cap_recs || (uint64_t)npc + np > (uint64_t)c.cap_pieces) {
+                cur = ~0ull;
+                break;
+            }
+            const unsigned long long want = cur + ((1ull << 32) | (unsigned long long)np);
+            if (__hip_atomic_compare_exchange_strong(c.cursor, &cur, want, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;  // cur = the value before our add
+        }
+        got = cur;
+    }
+    const uint32_t lo = __shfl((uint32_t)got, 0, 64), hi = __shfl((uint32_t)(got >> 32), 0, 64);
+    if ((lo & hi) == 0xFFFFFFFFu) return false;
+    const uint32_t slot = hi, pbase = lo;
+    for (uint32_t t = lane; t < np; t += 64u) c.piece_rec[pbase + t] = slot;
+    if (lane == 0) {
+        CutRecord r;
+        r.span_off = (uint64_t)(ptr - b.base);
+        r.span_len = len;
+        r.item = item;
+        r.piece_base = pbase;
+        r.np = np;
+        r.level = level;
+        r.cont = cont;
+        r.dlen = dlen;
+        r.pad[0] = r.pad[1] = 0u;
+        c.recs[slot] = r;
+    }
+    return true;
+}
+
 // Chunk::read (container.rs:47-66) by one wave on the serialized chunk at ptr,
 // `avail` bytes readable.  Returns SIFT_OK (0), Error::Read (1),
 // ReadInvalidChunkSize (3) or ReadCrcMismatch (5), raised in the reference's
 // order; *dlen is the chunk's data length once the length field has been read.
-__device__ __forceinline__ uint32_t read_chunk_wave(const uint8_t* ptr, uint64_t avail,
-                                                    uint32_t limit, uint32_t* dlen,
-                                                    const uint32_t* ldsY, const uint32_t* ldsX,
-                                                    uint32_t lane, uint32_t lane32, uint32_t aw) {
+// The checks that come before the CRC (:48-60) are split off so that the caller
+// can file a long chunk for the piece kernel between the two.
+__device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t avail,
+                                                    uint32_t limit, uint32_t* dlen) {
     *dlen = 0;
     if (avail < 4) return 1;                      // read_u32 fails, :48
     const uint32_t n = be32(ptr);
     if (n > limit) return 3;                      // :49-52
     *dlen = n;
     if (avail < 12ull + (uint64_t)n) return 1;    // read_exact on type / data / crc fails, :54-60
+    return 0;
+}
+
+__device__ __forceinline__ uint32_t read_chunk_wave(const uint8_t* ptr, uint64_t avail,
+                                                    uint32_t limit, uint32_t* dlen,
+                                                    const uint32_t* ldsY, const uint32_t* ldsX,
+                                                    uint32_t lane, uint32_t lane32, uint32_t aw) {
+    const uint32_t st = read_chunk_head(ptr, avail, limit, dlen);
+    if (st) return st;
+    const uint32_t n = *dlen;
     // container.rs:79-84: digest over type | data = ptr[4 .. 8+n), finalized
     const uint32_t crc =
         wave_crc(ptr + 4, 4ull + n, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
@@ -522,18 +600,10 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         } const it = {b.offsets[i], b.lens[i]};
         const uint8_t* ptr = b.base + it.offset;
         if (!b.verify) {
-            // Plain buffers, or pieces of longer buffers (b.states / b.dst set by
-            // the host): a piece starts from its own register and its raw result
-            // goes to the scratch array for crc32_stitch_kernel.
-            const uint32_t start = b.states ? b.states[i] : b.state;
-            const uint32_t r = wave_crc(ptr, it.len, start, ldsY, ldsX, lane, lane32, aw);
-            if (lane == 0) {
-                const uint32_t d = b.dst ? b.dst[i] : i;
-                if (d & 0x80000000u)
-                    b.scratch[d & 0x7FFFFFFFu] = r;
-                else
-                    b.out[d] = r ^ b.xor_out;
-            }
+            // crc.rs:28-34 on buffer i
+            if (file_span(b, i, ptr, it.len, 0u, 0u, lane)) continue;
+            const uint32_t r = wave_crc(ptr, it.len, b.state, ldsY, ldsX, lane, lane32, aw);
+            if (lane == 0) b.out[i] = r ^ b.xor_out;
             continue;
         }
         if (b.verify == 3) {
@@ -548,6 +618,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 if (it.len < 12ull + (uint64_t)dlen) status = 2;
             }
             if (status == 0) {
+                if (file_span(b, i, ptr + 4, 4ull + dlen, 0u, dlen, lane)) continue;
                 const uint32_t crc =
                     wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
                 if (lane < 4u)
@@ -562,8 +633,13 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         if (b.verify == 1) {
             // Chunk::read x n
             uint32_t dlen = 0;
-            const uint32_t status = read_chunk_wave(ptr, it.len, b.chunk_limit, &dlen, ldsY, ldsX,
-                                                    lane, lane32, aw);
+            uint32_t status = read_chunk_head(ptr, it.len, b.chunk_limit, &dlen);
+            if (status == 0) {
+                if (file_span(b, i, ptr + 4, 4ull + dlen, 0u, dlen, lane)) continue;
+                const uint32_t crc =
+                    wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
+                if (crc != be32(ptr + 8 + dlen)) status = 5;  // :60-63
+            }
             if (lane == 0) {
                 b.out[i] = status;
                 if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
@@ -584,13 +660,34 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 if (ptr[k] != magic[k]) status = 1;  // InvalidData (container.rs:113)
             pos = 9;
         }
+        bool amrg_filed = false;
         if (status == 0) {
-            status = read_chunk_wave(ptr + pos, it.len - pos, b.chunk_limit, &dlen, ldsY, ldsX, lane,
-                                     lane32, aw);
-            if (status == 0 && be32(ptr + pos + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
+            status = read_chunk_head(ptr + pos, it.len - pos, b.chunk_limit, &dlen);
             amrg_len = dlen;
-            pos += 12ull + dlen;
+            const uint64_t span = 4ull + dlen;
+            if (status == 0 && b.cut.cursor && span > (uint64_t)b.cut.wave_max) {
+                // A long AMRG chunk goes to the piece kernel.  Everything the
+                // reference does AFTER that chunk's CRC check is decided here, so the
+                // finisher only has to pick: CRC bad -> 5, else this verdict.
+                uint32_t cont = be32(ptr + pos + 4) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
+                if (cont == 0) {
+                    const uint64_t p2 = pos + 12ull + dlen;
+                    uint32_t d2 = 0;
+                    cont = read_chunk_wave(ptr + p2, it.len - p2, b.chunk_limit, &d2, ldsY, ldsX,
+                                           lane, lane32, aw);
+                    if (cont == 0 && be32(ptr + p2 + 4) != 0x53454E44u) cont = 1;  // expect_type(SEND)
+                }
+                amrg_filed = file_span(b, i, ptr + pos + 4, span, cont, dlen, lane);
+            }
+            if (status == 0 && !amrg_filed) {
+                const uint32_t crc =
+                    wave_crc(ptr + pos + 4, span, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
+                if (crc != be32(ptr + pos + 8 + dlen)) status = 5;
+                if (status == 0 && be32(ptr + pos + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
+                pos += 12ull + dlen;
+            }
         }
+        if (amrg_filed) continue;
         if (status == 0) {
             status = read_chunk_wave(ptr + pos, it.len - pos, b.chunk_limit, &dlen, ldsY, ldsX, lane,
                                      lane32, aw);
@@ -603,41 +700,197 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     }
 }
 
-// Buffers of a batch that were cut into pieces (all but the first kPiece
-// bytes long): Horner over the pieces' raw registers with x^(8*kPiece), one
-// wave per buffer, the constant multiply done by 32 lanes together.
-__global__ __launch_bounds__(256) void crc32_stitch_kernel(StitchArgs a) {
-    const uint32_t lane = threadIdx.x & 63u, k = threadIdx.x & 31u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * 4u;
-    const uint32_t row = a.piece_rows[k];  // x^(8*kPiece) * x^k
-    for (uint32_t s = wave; s < a.n; s += nwaves) {
-        const uint32_t first = a.first[s], count = a.count[s];
-        uint32_t r = a.scratch[first];
-        for (uint32_t j = 1; j < count; ++j) {
-            uint32_t t = ((r >> (31u - k)) & 1u) ? row : 0u;
+// ---------------------------------------------------------------------------
+// Piece kernel: the pieces the batch kernel filed, ONE WORKGROUP PER PIECE, with
+// the tile kernel's algorithm (16 KiB tiles, stride-one-tile Horner, y table
+// replicated per bank).  Piece j of a record covers
+//     [Eb - (np-j)*P, Eb - (np-1-j)*P),   Eb = end of the span rounded down to 16,
+// piece 0 starting at the span's first byte instead; its residue is weighted by
+// x^(8*P*(np-1-j)), so that the XOR of a record's residues is the register at Eb.
+// The kernel is persistent over the piece list: tables are staged once per
+// workgroup, and the workgroups stride through the list.
+__global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
+    constexpr int kZWords = 32 * 32;
+    __shared__ uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves];
+    uint32_t* ldsY = lds;
+    uint32_t* ldsX = lds + kYWords;
+    uint32_t* ldsZ = ldsX + kXWords;
+    uint32_t* red = ldsZ + kZWords;
+
+    const CutArgs& c = b.cut;
+    const uint32_t total = (uint32_t)*c.cursor;  // pieces reserved (never above cap_pieces)
+    if (blockIdx.x >= total) return;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
+    const uint32_t row32 = tid & 31u;
+#pragma unroll 16
+    for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y[i >> kReplLog2];
+    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
+    for (int i = tid; i < kZWords; i += kThreads) ldsZ[i] = (&b.tabs->X2[0][0])[i];
+    uint32_t kb[32];
+    kb[0] = b.tabs->Kt[tid];
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
-            r = t ^ a.scratch[first + j];
+    for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));
+    __syncthreads();
+
+    const uint32_t start_state = b.verify ? 0xFFFFFFFFu : b.state;
+    uint32_t parity = 0;
+    for (uint32_t p = blockIdx.x; p < total; p += gridDim.x, parity ^= 1u) {
+        const uint32_t slot = c.piece_rec[p];
+        const CutRecord* rp = c.recs + slot;
+        const uint64_t span_off = rp->span_off, span_len = rp->span_len;
+        const uint32_t np = rp->np, j = p - rp->piece_base;
+        const uint32_t plog = c.piece_min_log2 + rp->level;
+        const uint64_t A = reinterpret_cast<uint64_t>(b.base) + span_off;
+        const uint64_t Eb = (A + span_len) & ~15ull;
+        const uint64_t end_j = Eb - ((uint64_t)(np - 1u - j) << plog);
+        const uint64_t start_j = j == 0 ? (A & ~15ull) : end_j - (1ull << plog);
+        const int64_t nvec = (int64_t)((end_j - start_j) >> 4);
+        int64_t ntiles = (nvec + kTileVecs - 1) / kTileVecs;
+        const u32x4* vbase = reinterpret_cast<const u32x4*>(start_j);
+
+        // First tile: the only one that can be partial (tiles are aligned to the
+        // END of the piece); in piece 0 vector 0 carries the head mask and the
+        // starting register.
+        u32x4 acc = {0u, 0u, 0u, 0u};
+        const int64_t v0 = nvec - ntiles * (int64_t)kTileVecs;
+        const int64_t vi = v0 + (int64_t)tid;
+        if (vi >= 0) {
+            acc = load_vec(vbase + vi);
+            if (j == 0 && vi == 0) {
+                const uint32_t h = (uint32_t)(A & 15u);
+                if (h) acc = mask_head(acc, h);
+                acc[0] ^= h ? gf2_mulmod(start_state, b.tabs->XinvH[h]) : start_state;
+            }
         }
-        if (lane == 0) a.out[a.item[s]] = r ^ a.xor_out;
+        --ntiles;
+        const u32x4* pt = vbase + v0 + kTileVecs;
+        const uint32_t run_bytes = (uint32_t)ntiles * (uint32_t)kTileBytes;
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u32x4*>(pt), /*stride*/ 0, (int)run_bytes, 0x00020000);
+        const int voff = (int)(tid * 16u);
+        int soff = 0;
+        constexpr int U = kUnroll;
+        if (ntiles >= U) {
+            u32x4 cur[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
+            soff += U * kTileBytes;
+            ntiles -= U;
+            while (ntiles >= U) {
+                u32x4 nxt[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
+                soff += U * kTileBytes;
+                ntiles -= U;
+#pragma unroll
+                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+        }
+        while (ntiles > 0) {
+            const u32x4 w = load_tile(srd, voff, soff);
+            horner_step(acc, w, ldsY, lane32);
+            soff += kTileBytes;
+            --ntiles;
+        }
+
+        // Lane residue -> place in the tile -> XOR over the workgroup.
+        uint32_t r = 0;
+#pragma unroll
+        for (int cw = 0; cw < 4; ++cw) r = mul_x32(r ^ acc[cw], ldsX);
+        {
+            uint32_t prod = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) prod ^= kb[i] & (0u - ((r >> (31 - i)) & 1u));
+            r = prod;
+        }
+        r = wave_xor(r);
+        uint32_t* redp = red + parity * kWaves;  // two sets: wave 0 may still be reading the other
+        if ((tid & 63u) == 0) redp[tid >> 6] = r;
+        __syncthreads();
+        if (tid < 64u) {
+            uint32_t x = wave_xor(tid < (uint32_t)kWaves ? redp[tid] : 0u);
+            // weight x^(8 * 2^plog * k), k = pieces behind this one: the product of
+            // x^(2^(3+plog+bit)) over the set bits of k (x^(2^s) has period 32 in s)
+            uint32_t k = np - 1u - j;
+            for (uint32_t bit = 0; k; ++bit, k >>= 1)
+                if (k & 1u) x = mul_rows(x, ldsZ[((3u + plog + bit) & 31u) * 32u + row32], row32);
+            if (tid == 0) c.piece_res[p] = x;
+        }
     }
 }
 
-// Zeroes 64 words (two 128-B lines: accumulator, arrival counter) of a workspace.
+// Finisher: one wave per filed record.  XORs the record's weighted residues (the
+// register at the end of the span's body), walks the < 16 tail bytes, and does
+// what the batch kernel does after a wave_crc, per mode.
+__global__ __launch_bounds__(256) void crc32_cut_finish_kernel(BatchArgs b) {
+    const CutArgs& c = b.cut;
+    const uint32_t nrec = (uint32_t)(*c.cursor >> 32);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t s = wave; s < nrec; s += nwaves) {
+        const CutRecord* rp = c.recs + s;
+        const uint32_t np = rp->np, pbase = rp->piece_base;
+        uint32_t r = 0;
+        for (uint32_t t = lane; t < np; t += 256u) {
+            const uint32_t r0 = c.piece_res[pbase + t];
+            const uint32_t r1 = t + 64u < np ? c.piece_res[pbase + t + 64u] : 0u;
+            const uint32_t r2 = t + 128u < np ? c.piece_res[pbase + t + 128u] : 0u;
+            const uint32_t r3 = t + 192u < np ? c.piece_res[pbase + t + 192u] : 0u;
+            r ^= r0 ^ r1 ^ r2 ^ r3;
+        }
+        r = wave_xor(r);
+        if (lane != 0) continue;
+        const uint8_t* span = b.base + rp->span_off;
+        const uint8_t* end = span + rp->span_len;
+        const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
+        for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
+        const uint32_t item = rp->item;
+        if (!b.verify) {
+            b.out[item] = r ^ b.xor_out;
+            continue;
+        }
+        const uint32_t crc = r ^ 0xFFFFFFFFu;  // container.rs:83
+        uint32_t status;
+        if (b.verify == 3) {
+            uint8_t* slot = const_cast<uint8_t*>(end);
+            for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
+            status = 0;
+        } else {
+            status = crc == be32(end) ? rp->cont : 5u;  // container.rs:60-63, then what follows
+        }
+        b.out[item] = status;
+        if (b.data_len) b.data_len[item] = status == 0 ? rp->dlen : 0u;
+    }
+}
+
+// Zeroes 64 words (two 128-B lines) of a workspace.
 __global__ __launch_bounds__(64) void crc32_clear_kernel(uint32_t* words) { words[threadIdx.x] = 0u; }
 
 void launch_clear(uint32_t* words, void* stream) {
     hipLaunchKernelGGL(crc32_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), words);
 }
 
-void launch_stitch(const StitchArgs& a, int groups, void* stream) {
-    hipLaunchKernelGGL(crc32_stitch_kernel, dim3(groups), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
-}
-
 void launch_batch(const BatchArgs& b, int groups, void* stream) {
     hipLaunchKernelGGL(crc32_batch_kernel, dim3(groups), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), b);
+}
+
+void launch_pieces(const BatchArgs& b, int groups, void* stream) {
+    hipLaunchKernelGGL(crc32_pieces_kernel, dim3(groups), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), b);
+}
+
+void launch_cut_finish(const BatchArgs& b, int groups, void* stream) {
+    hipLaunchKernelGGL(crc32_cut_finish_kernel, dim3(groups), dim3(256), 0,
                        static_cast<hipStream_t>(stream), b);
 }
 
