@@ -730,7 +730,8 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     b.offsets = static_cast<const uint64_t*>(dv_off);
     b.lens = static_cast<const uint64_t*>(dv_len);
     if (cut) {
-        b.cut.cursor = reinterpret_cast<unsigned long long*>(d_tmp);
+        b.cut.counts = reinterpret_cast<uint32_t*>(d_tmp);
+        b.cut.pieces = reinterpret_cast<unsigned long long*>(d_tmp + 128);
         b.cut.recs = reinterpret_cast<CutRecord*>(d_tmp + 256);
         b.cut.piece_rec = reinterpret_cast<uint32_t*>(d_tmp + 256 + sizeof(CutRecord) * cap_recs);
         b.cut.piece_res = b.cut.piece_rec + cap_pieces;
@@ -738,7 +739,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         b.cut.cap_pieces = (uint32_t)cap_pieces;
         b.cut.wave_max = wave_max;
         b.cut.piece_min_log2 = (uint32_t)g_batch_piece_log2;
-        launch_clear(reinterpret_cast<uint32_t*>(d_tmp), stream);  // cursor = 0
+        launch_clear(reinterpret_cast<uint32_t*>(d_tmp), stream);  // both counters = 0
         SIFT_HIP(hipGetLastError());
     }
     const int waves_per_group = kThreads / 64;

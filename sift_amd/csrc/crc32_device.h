@@ -114,7 +114,8 @@ struct CombineMats {
 // only piece 0 has a ragged head and only the finisher sees the < 16 tail bytes.
 constexpr int kPieceMinLog2 = 16;            // 64 KiB: four 16 KiB tiles
 constexpr uint32_t kMaxPiecesPerItem = 1024; // level is raised until np fits (up to kMaxLevel)
-constexpr uint32_t kMaxLevel = 14;           // pieces of at most 1 GiB (32-bit buffer offsets)
+constexpr uint32_t kMaxLevel = 14;
+constexpr uint32_t kVoidSlot = 0xFFFFFFFFu;  // piece_rec entry of a reservation that did not fit           // pieces of at most 1 GiB (32-bit buffer offsets)
 
 struct CutRecord {
     uint64_t span_off;    // first byte of the CRC span, from BatchArgs::base
@@ -130,7 +131,8 @@ struct CutRecord {
 static_assert(sizeof(CutRecord) == 48, "CutRecord layout");
 
 struct CutArgs {
-    unsigned long long* cursor;  // hi 32 bits: records filed, lo 32 bits: pieces reserved; null = never cut
+    uint32_t* counts;            // records filed (may run past cap_recs); null = never cut
+    unsigned long long* pieces;  // piece slots reserved (may run past cap_pieces)
     CutRecord* recs;
     uint32_t* piece_rec;         // piece -> record slot
     uint32_t* piece_res;         // piece -> residue, weighted to the end of its span's body

@@ -497,7 +497,7 @@ __device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, con
                                           uint64_t len, uint32_t cont, uint32_t dlen,
                                           uint32_t lane) {
     const CutArgs& c = b.cut;
-    if (!c.cursor || len <= (uint64_t)c.wave_max) return false;
+    if (!c.counts || len <= (uint64_t)c.wave_max) return false;
     const uint64_t A = reinterpret_cast<uint64_t>(ptr);
     const uint64_t body = ((A + len) & ~15ull) - (A & ~15ull);  // whole vectors, > 0 here
     uint32_t level = 0;
@@ -508,28 +508,25 @@ __device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, con
     const uint64_t np64 = (body + (1ull << plog) - 1) >> plog;
     if (np64 > 0x40000000ull) return false;
     const uint32_t np = (uint32_t)np64;
-    // Reserve one record and np pieces together: one 64-bit word, records in the
-    // high half.  Compare-and-swap, so a reservation that does not fit changes
-    // nothing and the counts never pass the capacities.
-    unsigned long long got = ~0ull;
-    if (lane == 0) {
-        unsigned long long cur = __hip_atomic_load(c.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
-            const uint32_t nrec = (uint32_t)(cur >> 32), npc = (uint32_t)cur;
-            if (nrec >= c.cap_recs || (uint64_t)npc + np > (uint64_t)c.cap_pieces) {
-                cur = ~0ull;
-                break;
-            }
-            const unsigned long long want = cur + ((1ull << 32) | (unsigned long long)np);
-            if (__hip_atomic_compare_exchange_strong(c.cursor, &cur, want, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                break;  // cur = the value before our add
-        }
-        got = cur;
+    // Reserve a record slot and np piece slots: two independent atomic adds (plain
+    // adds, not compare-and-swap: a thousand waves filing at once would retry
+    // each other for milliseconds).  A reservation that does not fit is voided:
+    // whatever part of it lies inside the arrays is marked so that the piece
+    // kernel and the finisher skip it, and the caller walks the span itself.
+    uint32_t slot = 0;
+    unsigned long long pb = 0;
+    if (lane == 0) slot = __hip_atomic_fetch_add(c.counts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 1)
+        pb = __hip_atomic_fetch_add(c.pieces, (unsigned long long)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slot = __shfl(slot, 0, 64);
+    pb = ((unsigned long long)__shfl((uint32_t)(pb >> 32), 1, 64) << 32) | __shfl((uint32_t)pb, 1, 64);
+    if (slot >= c.cap_recs || pb + np > (unsigned long long)c.cap_pieces) {
+        if (lane == 0 && slot < c.cap_recs) c.recs[slot].np = 0u;
+        const unsigned long long stop = pb + np < c.cap_pieces ? pb + np : c.cap_pieces;
+        for (unsigned long long t = pb + lane; t < stop; t += 64u) c.piece_rec[t] = kVoidSlot;
+        return false;
     }
-    const uint32_t lo = __shfl((uint32_t)got, 0, 64), hi = __shfl((uint32_t)(got >> 32), 0, 64);
-    if ((lo & hi) == 0xFFFFFFFFu) return false;
-    const uint32_t slot = hi, pbase = lo;
+    const uint32_t pbase = (uint32_t)pb;
     for (uint32_t t = lane; t < np; t += 64u) c.piece_rec[pbase + t] = slot;
     if (lane == 0) {
         CutRecord r;
@@ -665,7 +662,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             status = read_chunk_head(ptr + pos, it.len - pos, b.chunk_limit, &dlen);
             amrg_len = dlen;
             const uint64_t span = 4ull + dlen;
-            if (status == 0 && b.cut.cursor && span > (uint64_t)b.cut.wave_max) {
+            if (status == 0 && b.cut.counts && span > (uint64_t)b.cut.wave_max) {
                 // A long AMRG chunk goes to the piece kernel.  Everything the
                 // reference does AFTER that chunk's CRC check is decided here, so the
                 // finisher only has to pick: CRC bad -> 5, else this verdict.
@@ -708,7 +705,12 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 // piece 0 starting at the span's first byte instead; its residue is weighted by
 // x^(8*P*(np-1-j)), so that the XOR of a record's residues is the register at Eb.
 // The kernel is persistent over the piece list: tables are staged once per
-// workgroup, and the workgroups stride through the list.
+// workgroup, and the workgroups stride through the list in windows of g pieces.
+// Pieces are small (64 KiB) so that one long item alone still spreads over the
+// chip; when the list is long the kernel, which knows its length, regroups:
+// neighbouring pieces of one record are adjacent in memory, so a run of them
+// inside a window is streamed as ONE longer piece (its residue stored for the
+// run's last piece, zero for the others).
 __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     constexpr int kZWords = 32 * 32;
     __shared__ uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves];
@@ -718,8 +720,12 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     uint32_t* red = ldsZ + kZWords;
 
     const CutArgs& c = b.cut;
-    const uint32_t total = (uint32_t)*c.cursor;  // pieces reserved (never above cap_pieces)
-    if (blockIdx.x >= total) return;
+    const unsigned long long reserved = *c.pieces;
+    const uint32_t total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
+    // window: about four per workgroup once the list is long enough, at most 64 pieces
+    uint32_t g = total / (gridDim.x * 4u);
+    g = g < 1u ? 1u : (g > 64u ? 64u : g);
+    if ((uint64_t)blockIdx.x * g >= total) return;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
@@ -738,16 +744,33 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
 
     const uint32_t start_state = b.verify ? 0xFFFFFFFFu : b.state;
     uint32_t parity = 0;
-    for (uint32_t p = blockIdx.x; p < total; p += gridDim.x, parity ^= 1u) {
+    uint64_t w = blockIdx.x;  // window index: this workgroup takes w, w + grid, ...
+    uint32_t p = (uint32_t)w * g, wend = p + g < total ? p + g : total;
+    for (;; parity ^= 1u) {
+        if (p >= wend) {
+            w += gridDim.x;
+            if (w * g >= total) break;
+            p = (uint32_t)(w * g);
+            wend = p + g < total ? p + g : total;
+        }
         const uint32_t slot = c.piece_rec[p];
+        if (slot == kVoidSlot) {  // reservation that did not fit: its span was walked in place
+            ++p;
+            continue;
+        }
         const CutRecord* rp = c.recs + slot;
         const uint64_t span_off = rp->span_off, span_len = rp->span_len;
         const uint32_t np = rp->np, j = p - rp->piece_base;
         const uint32_t plog = c.piece_min_log2 + rp->level;
+        // the run: pieces j .. j+run-1 of this record, inside the window, under 1 GiB
+        uint32_t run = wend - p;
+        if (run > np - j) run = np - j;
+        if (run > (1u << (30u - plog))) run = 1u << (30u - plog);
+        const uint32_t jl = j + run - 1u;  // last piece of the run: the run is weighted as jl is
         const uint64_t A = reinterpret_cast<uint64_t>(b.base) + span_off;
         const uint64_t Eb = (A + span_len) & ~15ull;
-        const uint64_t end_j = Eb - ((uint64_t)(np - 1u - j) << plog);
-        const uint64_t start_j = j == 0 ? (A & ~15ull) : end_j - (1ull << plog);
+        const uint64_t end_j = Eb - ((uint64_t)(np - 1u - jl) << plog);
+        const uint64_t start_j = j == 0 ? (A & ~15ull) : end_j - ((uint64_t)run << plog);
         const int64_t nvec = (int64_t)((end_j - start_j) >> 4);
         int64_t ntiles = (nvec + kTileVecs - 1) / kTileVecs;
         const u32x4* vbase = reinterpret_cast<const u32x4*>(start_j);
@@ -819,11 +842,12 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
             uint32_t x = wave_xor(tid < (uint32_t)kWaves ? redp[tid] : 0u);
             // weight x^(8 * 2^plog * k), k = pieces behind this one: the product of
             // x^(2^(3+plog+bit)) over the set bits of k (x^(2^s) has period 32 in s)
-            uint32_t k = np - 1u - j;
+            uint32_t k = np - 1u - jl;
             for (uint32_t bit = 0; k; ++bit, k >>= 1)
                 if (k & 1u) x = mul_rows(x, ldsZ[((3u + plog + bit) & 31u) * 32u + row32], row32);
-            if (tid == 0) c.piece_res[p] = x;
+            if (tid < run) c.piece_res[p + tid] = tid == run - 1u ? x : 0u;
         }
+        p += run;
     }
 }
 
@@ -832,13 +856,15 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
 // what the batch kernel does after a wave_crc, per mode.
 __global__ __launch_bounds__(256) void crc32_cut_finish_kernel(BatchArgs b) {
     const CutArgs& c = b.cut;
-    const uint32_t nrec = (uint32_t)(*c.cursor >> 32);
+    const uint32_t filed = *c.counts;
+    const uint32_t nrec = filed < c.cap_recs ? filed : c.cap_recs;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * 4u;
     for (uint32_t s = wave; s < nrec; s += nwaves) {
         const CutRecord* rp = c.recs + s;
         const uint32_t np = rp->np, pbase = rp->piece_base;
+        if (np == 0) continue;  // voided reservation
         uint32_t r = 0;
         for (uint32_t t = lane; t < np; t += 256u) {
             const uint32_t r0 = c.piece_res[pbase + t];

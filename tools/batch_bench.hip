@@ -1,0 +1,141 @@
+// batch_bench.hip -- host-wall and device time per call of the batch entry points,
+// without Python in the way.  Measurement tool, not part of the product.
+//   batch_bench                 runs the whole table
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/sift_amd.h"
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                   \
+            exit(2);                                                                  \
+        }                                                                             \
+    } while (0)
+#define SK(x)                                                                         \
+    do {                                                                              \
+        int r_ = (x);                                                                 \
+        if (r_ != SIFT_OK) {                                                          \
+            fprintf(stderr, "%s: %s (%s)\n", #x, sift_strerror(r_), sift_last_error()); \
+            exit(3);                                                                  \
+        }                                                                             \
+    } while (0)
+
+__global__ void fill(uint32_t* p, size_t nwords, uint32_t seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < nwords; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+        p[i] = x;
+    }
+}
+
+static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv) {
+    const size_t total = 1ull << 30;
+    uint8_t* blob = nullptr;
+    CK(hipMalloc(&blob, total + 4096));
+    fill<<<1024, 256>>>(reinterpret_cast<uint32_t*>(blob), (total + 4096) / 4, 0x51F7);
+    CK(hipDeviceSynchronize());
+    SK(sift_init(0));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    uint32_t* d_out = nullptr;
+    CK(hipMalloc(&d_out, 4ull << 20));
+    uint64_t *d_off = nullptr, *d_len = nullptr;
+    CK(hipMalloc(&d_off, 8ull << 20));
+    CK(hipMalloc(&d_len, 8ull << 20));
+    std::vector<uint64_t> off(1 << 20), len(1 << 20);
+
+    printf("{\"rows\": [\n");
+    bool first = true;
+    // plain buffers back to back in the blob, descriptors in HBM and on the host
+    const size_t sizes[] = {64, 1024, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
+    for (size_t size : sizes) {
+        const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
+        for (uint32_t i = 0; i < n; ++i) {
+            off[i] = (uint64_t)i * size;
+            len[i] = size;
+        }
+        CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
+        for (int where = 0; where < 2; ++where) {
+            const uint64_t* po = where ? off.data() : d_off;
+            const uint64_t* pl = where ? len.data() : d_len;
+            for (int i = 0; i < 3; ++i)
+                SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, po, pl, n, d_out, s));
+            CK(hipStreamSynchronize(s));
+            const int reps = 20;
+            CK(hipEventRecord(e0, s));
+            const double t0 = now();
+            for (int i = 0; i < reps; ++i)
+                SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, po, pl, n, d_out, s));
+            const double t_issue = now() - t0;
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            const double t_wall = now() - t0;
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%s {\"kind\": \"crc_batch\", \"descriptors\": \"%s\", \"buffer_bytes\": %zu, \"buffers\": %u, "
+                   "\"issue_us_per_call\": %.2f, \"wall_us_per_call\": %.2f, \"device_us_per_call\": %.2f, "
+                   "\"GBps_wall\": %.1f, \"GBps_device\": %.1f}",
+                   first ? "" : ",\n", where ? "host" : "device", size, n, t_issue / reps * 1e6, t_wall / reps * 1e6,
+                   ms * 1e3 / reps, (double)n * size / (t_wall / reps) / 1e9, (double)n * size / (ms * 1e-3 / reps) / 1e9);
+            first = false;
+            fflush(stdout);
+        }
+    }
+    // Chunk::read on ONE serialized chunk: length only in its header
+    for (size_t n : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20, ((size_t)1 << 30) - 16}) {
+        uint8_t hdr[8] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n, 'A', 'M', 'R', 'G'};
+        CK(hipMemcpy(blob, hdr, 8, hipMemcpyHostToDevice));
+        uint32_t crc = 0;
+        SK(sift_crc32_compute_device_sync(0, 0xFFFFFFFFu, blob + 4, n + 4, &crc, s));
+        crc ^= 0xFFFFFFFFu;
+        uint8_t be[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+        CK(hipMemcpy(blob + 8 + n, be, 4, hipMemcpyHostToDevice));
+        uint64_t o = 0, av = n + 12;
+        CK(hipMemcpy(d_off, &o, 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_len, &av, 8, hipMemcpyHostToDevice));
+        for (int i = 0; i < 3; ++i) SK(sift_read_chunks_device(0, blob, d_off, d_len, 1, d_out, d_out + 1, s));
+        CK(hipStreamSynchronize(s));
+        uint32_t st[2];
+        CK(hipMemcpy(st, d_out, 8, hipMemcpyDeviceToHost));
+        if (st[0] != 0 || st[1] != (uint32_t)n) {
+            fprintf(stderr, "chunk %zu: status %u len %u\n", n, st[0], st[1]);
+            return 4;
+        }
+        const int reps = 20;
+        CK(hipEventRecord(e0, s));
+        const double t0 = now();
+        for (int i = 0; i < reps; ++i) SK(sift_read_chunks_device(0, blob, d_off, d_len, 1, d_out, d_out + 1, s));
+        const double t_issue = now() - t0;
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        const double t_wall = now() - t0;
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf(",\n {\"kind\": \"read_one_chunk\", \"descriptors\": \"device\", \"chunk_data_bytes\": %zu, "
+               "\"issue_us_per_call\": %.2f, \"wall_us_per_call\": %.2f, \"device_us_per_call\": %.2f, "
+               "\"GBps_wall\": %.1f, \"GBps_device\": %.1f}",
+               n, t_issue / reps * 1e6, t_wall / reps * 1e6, ms * 1e3 / reps, (double)(n + 4) / (t_wall / reps) / 1e9,
+               (double)(n + 4) / (ms * 1e-3 / reps) / 1e9);
+        fflush(stdout);
+    }
+    printf("\n]}\n");
+    return 0;
+}

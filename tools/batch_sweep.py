@@ -55,6 +55,33 @@ for size in (64, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 
                  "device_descriptors_Mbuffers_per_s": round(n / ddt / 1e6, 2),
                  "gpu_GBps": round(n * size / dt / 1e9, 1), "gpu_Mbuffers_per_s": round(n / dt / 1e6, 2)})
     print(rows[-1], flush=True)
+
+# Chunk::read on ONE long serialized chunk (its length is only in its header, on the device)
+import struct
+chunk_rows = []
+for n in (1 << 20, 16 << 20, 64 << 20, 256 << 20, (1 << 30) - 16):
+    ser = torch.empty(n + 12, dtype=torch.uint8, device="cuda")
+    ser[8:8 + n] = blob[:n]
+    ser[:8] = torch.tensor(list(struct.pack(">I", n) + b"AMRG"), dtype=torch.uint8, device="cuda")
+    crc = sift_amd.compute(0xFFFFFFFF, ser[4:8 + n]) ^ 0xFFFFFFFF
+    ser[8 + n:] = torch.tensor(list(struct.pack(">I", crc)), dtype=torch.uint8, device="cuda")
+    doff = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dav = torch.full((1,), n + 12, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        st, _ = container.read_chunks_device(ser, doff, dav)
+    assert st.cpu().tolist() == [0]
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        container.read_chunks_device(ser, doff, dav)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    chunk_rows.append({"chunk_data_bytes": n, "read_chunks_device_us": round(dt * 1e6, 1),
+                       "GBps": round((n + 4) / dt / 1e9, 1)})
+    print(chunk_rows[-1], flush=True)
+    del ser
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "batch_sweep.json"), "w") as f:
     json.dump({"note": "sift_crc32_batch_device, buffers back to back in one 1 GiB device blob; time "
