@@ -58,8 +58,14 @@ const char *sift_last_error(void);
 /* Builds the per-device tables and scratch.  Optional: every compute call
  * initialises its device on first use.  Returns SIFT_OK or SIFT_ERR_*. */
 int sift_init(int device);
-/* Frees everything sift_init allocated on every device. */
+/* Frees everything the library allocated on every device. */
 void sift_shutdown(void);
+/* Waits for the device, then re-zeroes every piece of scratch the library keeps
+ * on it (per-stream workspaces, batch counters, the static array).  Between
+ * calls that scratch is zero by construction; only a kernel that was aborted
+ * half-way can leave it otherwise, and this puts it right.  No reference
+ * counterpart. */
+int sift_reset_workspace(int device);
 /* Bytes of device workspace one in-flight sift_crc32_compute_device call
  * needs when the caller brings its own (see `workspace` below).  A caller's
  * workspace must be zero-filled once before its first use; the library leaves
@@ -77,6 +83,10 @@ size_t sift_crc32_workspace_bytes(void);
  * bench.py divides algorithmic bytes by this for `roofline.achieved`. */
 int sift_profile_begin(int device, int max_launches, int stride);
 int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
+/* Same, and also copies the first `max_samples` per-launch kernel times (ms)
+ * into `samples_ms` (may be NULL). */
+int sift_profile_end_samples(int device, double *tile_kernel_ms, int *launches, float *samples_ms,
+                             int max_samples);
 
 /* Measurement knobs, process-wide.  No reference counterpart. */
 enum {
@@ -99,10 +109,15 @@ int sift_tune(int key, int value);
  * `state`, and stores the new running state to device address `d_out`
  * (4-byte aligned).  If `d_state_in` is non-NULL the starting state is read
  * from that device word instead of `state` (lets Digest::update calls chain
- * on a stream with no host round trip).  `workspace` is either NULL (the
- * library's internal per-device scratch ring is used; calls in flight at the
- * same time on one device then share a ring of 64 slots) or a device buffer
- * of sift_crc32_workspace_bytes() that no other in-flight call uses.
+ * on a stream with no host round trip).  `workspace` is either a device buffer
+ * of sift_crc32_workspace_bytes() that no other in-flight call uses, or NULL:
+ * the library then uses the workspace it keeps for `stream` (one per stream,
+ * allocated and zeroed on that stream's first call, so that first call
+ * allocates; calls on one stream run in order and share it safely, calls on
+ * different streams never share one, however many are in flight).  Under HIP
+ * graph capture a NULL workspace is refused (SIFT_ERR_INVALID_ARG): a graph may
+ * replay on any stream, so bring a workspace, or use
+ * sift_crc32_compute_device_static.
  */
 int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_state_in,
                               const void *d_buf, uint64_t len, uint32_t *d_out,
@@ -173,13 +188,21 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
 /* ------------------------------------------------ many buffers at once -----
  * The data-parallel form of the two functions above, for callers that hold
  * many independent buffers / serialized chunks in HBM (bulk load of many
- * files).  One wave per buffer; in crc mode with host descriptors a buffer
- * over 256 KiB is cut into 256 KiB pieces (one wave each, stitched by a second
- * small kernel) and one of 64 MiB or more takes the whole-chip path.  `offsets` / `lens` are arrays of n entries
- * (byte offset from `d_base`, byte length), both in host memory or both in
- * device memory; device arrays are used in place (nothing is copied, and every
- * buffer is then reduced by one wave whatever its length).  Results go to
- * device memory, asynchronously on `stream`.
+ * files).  `offsets` / `lens` are arrays of n entries (byte offset from `d_base`,
+ * byte length): both device arrays (used in place), or host arrays (pinned ones
+ * are read in place by the GPU, pageable ones are copied to the device first).
+ * Short items are reduced by one wave each.  An item whose CRC span is long
+ * (over 256 KiB when n >= 4096, over 32 KiB otherwise) is cut ON THE DEVICE --
+ * in the chunk modes the length is only in the chunk's header -- into pieces of
+ * 64 KiB and up that whole workgroups reduce, so one 1 GiB chunk, 64 chunks of
+ * 16 MiB and a million 64-byte chunks all run near the memory rate, whether the
+ * descriptors came from the host or not.  Results go to device memory,
+ * asynchronously on `stream`.  Scratch (a few hundred KiB, more for `d_base`
+ * allocations beyond 1 GiB) is kept per stream and allocated when first needed;
+ * the calls cannot be captured into a HIP graph.  Items that overlap each other
+ * in memory are allowed; if there are so many long overlapping ones that the
+ * scratch sized for non-overlapping items fills up, the rest are walked by one
+ * wave each (same results, slower).
  *
  * sift_crc32_batch_device:  d_out[i] = compute(state, buffer i) ^ xor_out
  *                           (crc.rs:28-34 applied n times; state = 0xFFFFFFFF,
@@ -190,11 +213,7 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  *                           SIFT_ERR_READ_INVALID_CHUNK_SIZE or
  *                           SIFT_ERR_READ_CRC_MISMATCH, raised in the reference's
  *                           order; d_data_len[i] (optional, may be NULL) = data
- *                           length of chunk i if it parsed, else 0.  A chunk's
- *                           length is only known on the device, so each chunk is
- *                           checked by one wave whatever its size: meant for many
- *                           small chunks; check a single large chunk with
- *                           sift_chunk_crc_device (whole chip) instead.
+ *                           length of chunk i if it parsed, else 0.
  * sift_read_documents_device: the framing of read_document (document.rs:62-77)
  *                           on n whole save files: read_header, read_chunk +
  *                           expect_type(AMRG), read_chunk + expect_type(SEND).

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/sift_amd.h"
@@ -25,11 +27,11 @@ thread_local std::string g_last_error;
 // Finish inside the tile kernel (last group to arrive combines) instead of a
 // second launch.  sift_tune(SIFT_TUNE_SINGLE_LAUNCH, 0) selects the two-launch
 // form for A/B measurement.
-bool g_single_launch = true;
+std::atomic<bool> g_single_launch{true};
 // Tuning knobs of the batch entry points (sift_tune).
-int g_batch_cut = 1;          // 0: every item stays on one wave (round-1 behaviour, A/B only)
-int g_batch_wave_max = 0;     // bytes a single wave keeps; 0 = chosen from n (run_batch)
-int g_batch_piece_log2 = kPieceMinLog2;
+std::atomic<int> g_batch_cut{1};          // 0: every item stays on one wave (round-1 behaviour, A/B only)
+std::atomic<int> g_batch_wave_max{0};     // bytes a single wave keeps; 0 = chosen from n (run_batch)
+std::atomic<int> g_batch_piece_log2{kPieceMinLog2};
 
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -42,7 +44,6 @@ int fail_hip(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return fail_hip(e__, #call); \
     } while (0)
 
-constexpr int kRingSlots = 64;
 // Workspace slot, in u32 words: residues (two-launch form) | pad |
 // u64 XOR accumulator (own 128-B line) | u64 arrival counter (own line).
 constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32 words on
@@ -63,26 +64,35 @@ const X2nTable& x2n() {
     return t;
 }
 
+// Device scratch of the calls issued on one stream.  Calls on one stream run in
+// order on the device, so they can share a block; calls on different streams
+// may overlap, so every stream gets blocks of its own (allocated on its first
+// call, kept until sift_shutdown).  Nothing is handed out round-robin: there is
+// no state that a call still in flight on another stream could be sharing.
+struct StreamScratch {
+    uint32_t* compute_ws = nullptr;  // kSlotWords, zero between calls (sift_crc32_compute_* with workspace NULL)
+    uint8_t* batch = nullptr;        // batch entry points: counters | records | piece list; counters zero between calls
+    size_t batch_bytes = 0;
+};
+
 struct DeviceCtx {
     int device = -1;
     int groups_max = 0;  // workgroups per launch = CUs (one 132 KiB-LDS workgroup per CU)
     DeviceTables* d_tabs = nullptr;
-    uint32_t* d_ring = nullptr;  // kRingSlots * kSlotWords
     uint32_t* static_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
-    unsigned ring_next = 0;
+    std::mutex scratch_mutex;            // guards per_stream, and a batch call's launch sequence
+    std::unordered_map<hipStream_t, StreamScratch> per_stream;
     // host-input staging (sift_crc32_compute_host)
+    bool staging_ready = false;
     uint8_t* d_stage[2] = {nullptr, nullptr};
     uint32_t* d_state = nullptr;  // chained running state for staged pieces
     // Results of the synchronous entry points land in pinned host memory the
     // GPU writes directly (no device->host copy command): 64 slots, 64 B apart.
     uint32_t* h_results = nullptr;
-    unsigned h_next = 0;
+    std::atomic<unsigned> h_next{0};
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     std::mutex host_path_mutex;
-    // measurement support (sift_profile_begin / _end): event pairs around the
-    // tile kernel of each launch, recorded on the launch's own stream
-    std::vector<hipEvent_t> prof_events;
     struct MatsEntry {
         int64_t tpg = -1;
         int groups = -1;
@@ -91,10 +101,34 @@ struct DeviceCtx {
     std::array<MatsEntry, 8> mats_cache;
     unsigned mats_next = 0;
     std::mutex mats_mutex;
+    // measurement support (sift_profile_begin / _end): event pairs around the
+    // tile kernel of each launch, recorded on the launch's own stream
+    std::mutex prof_mutex;
+    std::vector<hipEvent_t> prof_events;
     int prof_used = 0;
     int prof_stride = 1, prof_seen = 0;
     bool prof_on = false;
 };
+
+void destroy_ctx(DeviceCtx* c) {  // the device is current
+    if (!c) return;
+    (void)hipFree(c->d_tabs);
+    (void)hipFree(c->d_state);
+    if (c->h_results) (void)hipHostFree(c->h_results);
+    for (auto& kv : c->per_stream) {
+        (void)hipFree(kv.second.compute_ws);
+        (void)hipFree(kv.second.batch);
+    }
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+        if (c->copied[i]) (void)hipEventDestroy(c->copied[i]);
+        if (c->consumed[i]) (void)hipEventDestroy(c->consumed[i]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->work_stream) (void)hipStreamDestroy(c->work_stream);
+    delete c;
+}
 
 std::mutex g_ctx_mutex;
 std::vector<DeviceCtx*> g_ctx;  // indexed by device
@@ -131,6 +165,35 @@ void build_tables(DeviceTables* t) {
     }
 }
 
+// RAII device switch for calls that allocate or launch.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
+            ok = true;
+    }
+    ~DeviceGuard() {
+        if (ok && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int init_ctx(DeviceCtx* c, int device) {  // the device is current
+    c->device = device;
+    hipDeviceProp_t prop;
+    SIFT_HIP(hipGetDeviceProperties(&prop, device));
+    c->groups_max = std::max(1, std::min(prop.multiProcessorCount * kGroupsPerCu, kMaxGroups));
+    std::vector<DeviceTables> h(1);
+    build_tables(h.data());
+    SIFT_HIP(hipMalloc(&c->d_tabs, sizeof(DeviceTables)));
+    SIFT_HIP(hipMemcpy(c->d_tabs, h.data(), sizeof(DeviceTables), hipMemcpyHostToDevice));
+    SIFT_HIP(hipMalloc(&c->d_state, 256));
+    // This device's address of the static scratch array (this device is current).
+    SIFT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&c->static_scratch), HIP_SYMBOL(scratch)));
+    SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), 64 * 64, hipHostMallocDefault));
+    return SIFT_OK;
+}
+
 int get_ctx(int device, DeviceCtx** out) {
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     int count = 0;
@@ -149,43 +212,23 @@ int get_ctx(int device, DeviceCtx** out) {
         *out = g_ctx[device];
         return SIFT_OK;
     }
-    int prev = 0;
-    SIFT_HIP(hipGetDevice(&prev));
-    SIFT_HIP(hipSetDevice(device));
+    // Build into a local and publish only on full success; the caller's current
+    // device is restored on every path.
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
     DeviceCtx* c = new DeviceCtx;
-    c->device = device;
-    hipDeviceProp_t prop;
-    SIFT_HIP(hipGetDeviceProperties(&prop, device));
-    c->groups_max = std::max(1, std::min(prop.multiProcessorCount * kGroupsPerCu, kMaxGroups));
-    DeviceTables* h = new DeviceTables;
-    build_tables(h);
-    SIFT_HIP(hipMalloc(&c->d_tabs, sizeof(DeviceTables)));
-    SIFT_HIP(hipMemcpy(c->d_tabs, h, sizeof(DeviceTables), hipMemcpyHostToDevice));
-    delete h;
-    SIFT_HIP(hipMalloc(&c->d_ring, kRingSlots * kSlotWords * sizeof(uint32_t)));
-    SIFT_HIP(hipMemset(c->d_ring, 0, kRingSlots * kSlotWords * sizeof(uint32_t)));
-    SIFT_HIP(hipMalloc(&c->d_state, 256));
-    // This device's address of the static scratch array (this device is current).
-    SIFT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&c->static_scratch), HIP_SYMBOL(scratch)));
-    SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), 64 * 64, hipHostMallocDefault));
-    SIFT_HIP(hipSetDevice(prev));
+    const int rc = init_ctx(c, device);
+    if (rc != SIFT_OK) {
+        destroy_ctx(c);
+        return rc;
+    }
     g_ctx[device] = c;
     *out = c;
     return SIFT_OK;
 }
-
-// RAII device switch for calls that allocate or launch.
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess))
-            ok = true;
-    }
-    ~DeviceGuard() {
-        if (ok && prev >= 0) (void)hipSetDevice(prev);
-    }
-};
 
 // x^(-8h) mod P for h = 0..15 (P is primitive: x^-k = x^(2^32-1-k)).
 const uint32_t* xinv8() {
@@ -298,15 +341,21 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
         std::memset(&m, 0, sizeof(m));
     }
 
-    const bool prof = c->prof_on && (c->prof_seen++ % c->prof_stride) == 0 &&
-                      (size_t)(2 * c->prof_used + 1) < c->prof_events.size();
-    if (prof) SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used], stream));
+    // measurement: bracket this launch's tile kernel with an event pair
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->prof_mutex);
+        if (c->prof_on && (c->prof_seen++ % c->prof_stride) == 0 &&
+            (size_t)(2 * c->prof_used + 1) < c->prof_events.size()) {
+            ev0 = c->prof_events[2 * c->prof_used];
+            ev1 = c->prof_events[2 * c->prof_used + 1];
+            ++c->prof_used;
+        }
+    }
+    if (ev0) SIFT_HIP(hipEventRecord(ev0, stream));
     launch_tiles(t, f, m, (int)groups, tpg > 1, stream);
     SIFT_HIP(hipGetLastError());
-    if (prof) {
-        SIFT_HIP(hipEventRecord(c->prof_events[2 * c->prof_used + 1], stream));
-        ++c->prof_used;
-    }
+    if (ev1) SIFT_HIP(hipEventRecord(ev1, stream));
     if (groups > 1 && !t.single_launch) {
         launch_combine(workspace, f, m, stream);
         SIFT_HIP(hipGetLastError());
@@ -315,25 +364,55 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
 }
 
 volatile uint32_t* result_slot(DeviceCtx* c) {
-    std::lock_guard<std::mutex> lock(g_ctx_mutex);
-    return c->h_results + (size_t)(c->h_next++ % 64) * 16;
+    return c->h_results + (size_t)(c->h_next.fetch_add(1) % 64) * 16;
 }
 
-uint32_t* ring_slot(DeviceCtx* c) {
-    std::lock_guard<std::mutex> lock(g_ctx_mutex);
-    unsigned i = c->ring_next++ % kRingSlots;
-    return c->d_ring + (size_t)i * kSlotWords;
-}
-
-int ensure_staging(DeviceCtx* c) {
-    if (c->d_stage[0]) return SIFT_OK;
-    for (int i = 0; i < 2; ++i) {
-        SIFT_HIP(hipMalloc(&c->d_stage[i], kStagePiece));
-        SIFT_HIP(hipEventCreateWithFlags(&c->copied[i], hipEventDisableTiming));
-        SIFT_HIP(hipEventCreateWithFlags(&c->consumed[i], hipEventDisableTiming));
+// True when `stream` is being captured into a graph.  The library's own scratch
+// is tied to the stream a call is issued on; a captured call would bake that
+// block into a graph that may later replay on any stream, beside eager calls
+// on this one.  Entry points that would use library scratch refuse instead.
+bool capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
     }
-    SIFT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    SIFT_HIP(hipStreamCreateWithFlags(&c->work_stream, hipStreamNonBlocking));
+    return st != hipStreamCaptureStatusNone;
+}
+
+// The compute workspace of `stream` (created zeroed on the stream's first call).
+int stream_workspace(DeviceCtx* c, hipStream_t stream, uint32_t** ws) {
+    if (capturing(stream)) {
+        g_last_error = "stream is being captured: pass a workspace of sift_crc32_workspace_bytes(), or use "
+                       "sift_crc32_compute_device_static (the library's per-stream scratch cannot go into a graph)";
+        return SIFT_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    StreamScratch& ss = c->per_stream[stream];
+    if (!ss.compute_ws) {
+        uint32_t* p = nullptr;
+        SIFT_HIP(hipMalloc(&p, kSlotWords * sizeof(uint32_t)));
+        hipError_t e = hipMemset(p, 0, kSlotWords * sizeof(uint32_t));  // synchronous: done before any launch
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail_hip(e, "hipMemset(workspace)");
+        }
+        ss.compute_ws = p;
+    }
+    *ws = ss.compute_ws;
+    return SIFT_OK;
+}
+
+int ensure_staging(DeviceCtx* c) {  // under host_path_mutex
+    if (c->staging_ready) return SIFT_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!c->d_stage[i]) SIFT_HIP(hipMalloc(&c->d_stage[i], kStagePiece));
+        if (!c->copied[i]) SIFT_HIP(hipEventCreateWithFlags(&c->copied[i], hipEventDisableTiming));
+        if (!c->consumed[i]) SIFT_HIP(hipEventCreateWithFlags(&c->consumed[i], hipEventDisableTiming));
+    }
+    if (!c->copy_stream) SIFT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->work_stream) SIFT_HIP(hipStreamCreateWithFlags(&c->work_stream, hipStreamNonBlocking));
+    c->staging_ready = true;  // set last: a partial failure above is retried, not skipped
     return SIFT_OK;
 }
 
@@ -372,21 +451,28 @@ void sift_shutdown(void) {
         if (!c) continue;
         DeviceGuard guard(c->device);
         (void)hipDeviceSynchronize();
-        (void)hipFree(c->d_tabs);
-        (void)hipFree(c->d_ring);
-        (void)hipFree(c->d_state);
-        (void)hipHostFree(c->h_results);
-        for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
-        for (int i = 0; i < 2; ++i) {
-            if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
-            if (c->copied[i]) (void)hipEventDestroy(c->copied[i]);
-            if (c->consumed[i]) (void)hipEventDestroy(c->consumed[i]);
-        }
-        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-        if (c->work_stream) (void)hipStreamDestroy(c->work_stream);
-        delete c;
+        destroy_ctx(c);
     }
     g_ctx.clear();
+}
+
+int sift_reset_workspace(int device) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    SIFT_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    for (auto& kv : c->per_stream) {
+        if (kv.second.compute_ws) SIFT_HIP(hipMemset(kv.second.compute_ws, 0, kSlotWords * sizeof(uint32_t)));
+        if (kv.second.batch) SIFT_HIP(hipMemset(kv.second.batch, 0, kCutHeadBytes));
+    }
+    SIFT_HIP(hipMemset(c->static_scratch, 0, kStaticScratchWords * sizeof(uint32_t)));
+    return SIFT_OK;
 }
 
 int sift_profile_begin(int device, int max_launches, int stride) {
@@ -394,6 +480,7 @@ int sift_profile_begin(int device, int max_launches, int stride) {
     int rc = get_ctx(device, &c);
     if (rc != SIFT_OK) return rc;
     DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(c->prof_mutex);
     if (max_launches < 0) max_launches = 0;
     while ((int)c->prof_events.size() < 2 * max_launches) {
         hipEvent_t e;
@@ -408,10 +495,16 @@ int sift_profile_begin(int device, int max_launches, int stride) {
 }
 
 int sift_profile_end(int device, double* tile_kernel_ms, int* launches) {
+    return sift_profile_end_samples(device, tile_kernel_ms, launches, nullptr, 0);
+}
+
+int sift_profile_end_samples(int device, double* tile_kernel_ms, int* launches, float* samples_ms,
+                             int max_samples) {
     DeviceCtx* c = nullptr;
     int rc = get_ctx(device, &c);
     if (rc != SIFT_OK) return rc;
     DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(c->prof_mutex);
     c->prof_on = false;
     double total = 0.0;
     for (int i = 0; i < c->prof_used; ++i) {
@@ -419,6 +512,7 @@ int sift_profile_end(int device, double* tile_kernel_ms, int* launches) {
         float ms = 0.f;
         SIFT_HIP(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
         total += ms;
+        if (samples_ms && i < max_samples) samples_ms[i] = ms;
     }
     if (tile_kernel_ms) *tile_kernel_ms = total;
     if (launches) *launches = c->prof_used;
@@ -463,7 +557,8 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t* d_stat
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    uint32_t* ws = workspace ? static_cast<uint32_t*>(workspace) : ring_slot(c);
+    uint32_t* ws = static_cast<uint32_t*>(workspace);
+    if (!ws && (rc = stream_workspace(c, static_cast<hipStream_t>(stream), &ws)) != SIFT_OK) return rc;
     return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws,
                           static_cast<hipStream_t>(stream));
 }
@@ -519,9 +614,10 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    uint32_t* ws = ring_slot(c);
-    volatile uint32_t* res = result_slot(c);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* ws = nullptr;
+    if ((rc = stream_workspace(c, s, &ws)) != SIFT_OK) return rc;
+    volatile uint32_t* res = result_slot(c);
     rc = launch_compute(c, state, nullptr, d_buf, len, 0u, const_cast<uint32_t*>(res), ws, s);
     if (rc != SIFT_OK) return rc;
     SIFT_HIP(hipStreamSynchronize(s));
@@ -548,7 +644,8 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     if (rc != SIFT_OK) return rc;
 
     const uint8_t* src = static_cast<const uint8_t*>(buf);
-    uint32_t* ws = ring_slot(c);
+    uint32_t* ws = nullptr;
+    if ((rc = stream_workspace(c, c->work_stream, &ws)) != SIFT_OK) return rc;
     volatile uint32_t* res = result_slot(c);
 
     // Pinned (hipHostMalloc / hipHostRegister) input is device-addressable: the
@@ -572,23 +669,36 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     // result provably comes from the device path.
     uint64_t off = 0;
     int piece = 0;
+    // An error in the middle leaves copies from the caller's buffer in flight:
+    // drain both streams before handing the buffer back.
+    auto bail = [&](int code) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->work_stream);
+        return code;
+    };
+#define SIFT_STAGE(call)                                          \
+    do {                                                          \
+        hipError_t e__ = (call);                                  \
+        if (e__ != hipSuccess) return bail(fail_hip(e__, #call)); \
+    } while (0)
     do {
         const uint64_t n = std::min<uint64_t>(kStagePiece, len - off);
         const int b = piece & 1;
-        if (piece >= 2) SIFT_HIP(hipStreamWaitEvent(c->copy_stream, c->consumed[b], 0));
+        if (piece >= 2) SIFT_STAGE(hipStreamWaitEvent(c->copy_stream, c->consumed[b], 0));
         if (n)
-            SIFT_HIP(hipMemcpyAsync(c->d_stage[b], src + off, n, hipMemcpyHostToDevice,
-                                    c->copy_stream));
-        SIFT_HIP(hipEventRecord(c->copied[b], c->copy_stream));
-        SIFT_HIP(hipStreamWaitEvent(c->work_stream, c->copied[b], 0));
+            SIFT_STAGE(hipMemcpyAsync(c->d_stage[b], src + off, n, hipMemcpyHostToDevice,
+                                      c->copy_stream));
+        SIFT_STAGE(hipEventRecord(c->copied[b], c->copy_stream));
+        SIFT_STAGE(hipStreamWaitEvent(c->work_stream, c->copied[b], 0));
         const bool last = off + n >= len;
         rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_stage[b], n, 0u,
                             last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream);
-        if (rc != SIFT_OK) return rc;
-        SIFT_HIP(hipEventRecord(c->consumed[b], c->work_stream));
+        if (rc != SIFT_OK) return bail(rc);
+        SIFT_STAGE(hipEventRecord(c->consumed[b], c->work_stream));
         off += n;
         ++piece;
     } while (off < len);
+#undef SIFT_STAGE
     SIFT_HIP(hipStreamSynchronize(c->work_stream));
     *out = *res;
     return SIFT_OK;
@@ -639,12 +749,11 @@ Where where_is(const void* p, const void** dev_ptr) {
     return Where::Host;
 }
 
-// The batch entry points.  Three launches on `stream`:
-//   1. crc32_batch_kernel       one wave per item; an item whose CRC span is long
-//                               is filed (record + pieces) instead of walked
-//   2. crc32_pieces_kernel      one workgroup per filed piece (tile algorithm)
-//   3. crc32_cut_finish_kernel  one wave per filed record: XOR of its residues,
-//                               tail bytes, verdict
+// The batch entry points.  Two launches on `stream`:
+//   1. crc32_batch_kernel   one wave per item; an item whose CRC span is long is
+//                           filed (record + pieces) instead of walked
+//   2. crc32_pieces_kernel  one workgroup per run of filed pieces (tile algorithm);
+//                           the run that completes a record gives the item its verdict
 // The lengths that decide what is long are read on the device (from `lens`, or
 // from each chunk's header in the verify modes), so it makes no difference
 // whether the descriptors came from the host or were already in HBM.
@@ -696,9 +805,10 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // extent / wave_max records, and a record of body B has at most B / piece + 1
     // pieces.  Items that overlap can exceed this; a span that finds the arrays
     // full is walked by its own wave instead (same bits, slower).
-    const bool cut = g_batch_cut != 0;
-    const uint32_t wave_max = g_batch_wave_max > 0 ? (uint32_t)g_batch_wave_max
-                                                   : (n >= 4096u ? (256u << 10) : (32u << 10));
+    const bool cut = g_batch_cut.load() != 0;
+    const int tuned_wave_max = g_batch_wave_max.load(), piece_log2 = g_batch_piece_log2.load();
+    const uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max
+                                                 : (n >= 4096u ? (256u << 10) : (32u << 10));
     uint64_t extent = 1ull << 30;
     {
         hipDeviceptr_t abase = nullptr;
@@ -710,50 +820,66 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         }
     }
     const uint64_t cap_recs = std::min<uint64_t>(n, extent / wave_max + 1);
-    const uint64_t cap_pieces = std::min<uint64_t>((extent >> g_batch_piece_log2) + cap_recs + 1, 0x7FFFFFFFull);
-    const size_t copy_bytes = (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
-    const size_t cut_bytes = cut ? 256 + sizeof(CutRecord) * cap_recs + 8 * cap_pieces : 0;
-    uint8_t* d_tmp = nullptr;
-    if (copy_bytes + cut_bytes)
-        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tmp), cut_bytes + copy_bytes, stream));
-    uint8_t* d_desc = d_tmp + cut_bytes;
-    if (w_off == Where::Host) {
-        // pageable source: the runtime has consumed it when the call returns
-        SIFT_HIP(hipMemcpyAsync(d_desc, offsets, 8ull * n, hipMemcpyHostToDevice, stream));
-        dv_off = d_desc;
-        d_desc += 8ull * n;
+    const uint64_t cap_pieces = std::min<uint64_t>((extent >> piece_log2) + cap_recs + 1, 0x7FFFFFFFull);
+    hipStream_t st = stream;
+    if (capturing(st)) {
+        g_last_error = "the batch entry points cannot be captured into a graph (their scratch belongs to the stream)";
+        return SIFT_ERR_INVALID_ARG;
     }
-    if (w_len == Where::Host) {
-        SIFT_HIP(hipMemcpyAsync(d_desc, lens, 8ull * n, hipMemcpyHostToDevice, stream));
-        dv_len = d_desc;
-    }
-    b.offsets = static_cast<const uint64_t*>(dv_off);
-    b.lens = static_cast<const uint64_t*>(dv_len);
+    // One batch call at a time issues its launch sequence per device: the scratch
+    // block of a stream is shared by that stream's calls in stream order.
+    std::lock_guard<std::mutex> lock(c->scratch_mutex);
     if (cut) {
-        b.cut.counts = reinterpret_cast<uint32_t*>(d_tmp);
-        b.cut.pieces = reinterpret_cast<unsigned long long*>(d_tmp + 128);
-        b.cut.recs = reinterpret_cast<CutRecord*>(d_tmp + 256);
-        b.cut.piece_rec = reinterpret_cast<uint32_t*>(d_tmp + 256 + sizeof(CutRecord) * cap_recs);
-        b.cut.piece_res = b.cut.piece_rec + cap_pieces;
+        StreamScratch& ss = c->per_stream[st];
+        const size_t need = kCutHeadBytes + sizeof(CutRecord) * cap_recs + 4 * cap_pieces;
+        if (ss.batch_bytes < need) {
+            // grow-only; the old block is freed in stream order, behind the calls that used it
+            const size_t want = std::max<size_t>(need + need / 2, 512u << 10);
+            uint8_t* fresh = nullptr;
+            SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&fresh), want, st));
+            launch_clear(reinterpret_cast<uint32_t*>(fresh), st);  // the three counters
+            SIFT_HIP(hipGetLastError());
+            if (ss.batch) SIFT_HIP(hipFreeAsync(ss.batch, st));
+            ss.batch = fresh;
+            ss.batch_bytes = want;
+        }
+        uint8_t* blk = ss.batch;
+        b.cut.counts = reinterpret_cast<uint32_t*>(blk);
+        b.cut.left = reinterpret_cast<uint32_t*>(blk + 64);
+        b.cut.pieces = reinterpret_cast<unsigned long long*>(blk + 128);
+        b.cut.recs = reinterpret_cast<CutRecord*>(blk + kCutHeadBytes);
+        b.cut.piece_rec = reinterpret_cast<uint32_t*>(blk + kCutHeadBytes + sizeof(CutRecord) * cap_recs);
         b.cut.cap_recs = (uint32_t)cap_recs;
         b.cut.cap_pieces = (uint32_t)cap_pieces;
         b.cut.wave_max = wave_max;
-        b.cut.piece_min_log2 = (uint32_t)g_batch_piece_log2;
-        launch_clear(reinterpret_cast<uint32_t*>(d_tmp), stream);  // both counters = 0
-        SIFT_HIP(hipGetLastError());
+        b.cut.piece_min_log2 = (uint32_t)piece_log2;
     }
+    const size_t copy_bytes = (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
+    uint8_t* d_desc = nullptr;
+    if (copy_bytes) SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), copy_bytes, st));
+    uint8_t* d_next = d_desc;
+    if (w_off == Where::Host) {
+        // pageable source: the runtime has consumed it when the call returns
+        SIFT_HIP(hipMemcpyAsync(d_next, offsets, 8ull * n, hipMemcpyHostToDevice, st));
+        dv_off = d_next;
+        d_next += 8ull * n;
+    }
+    if (w_len == Where::Host) {
+        SIFT_HIP(hipMemcpyAsync(d_next, lens, 8ull * n, hipMemcpyHostToDevice, st));
+        dv_len = d_next;
+    }
+    b.offsets = static_cast<const uint64_t*>(dv_off);
+    b.lens = static_cast<const uint64_t*>(dv_len);
     const int waves_per_group = kThreads / 64;
     const int groups = (int)std::min<uint64_t>(((uint64_t)n + waves_per_group - 1) / waves_per_group,
                                                (uint64_t)c->groups_max);
-    launch_batch(b, groups, stream);
+    launch_batch(b, groups, st);
     SIFT_HIP(hipGetLastError());
     if (cut) {
-        launch_pieces(b, c->groups_max, stream);
-        SIFT_HIP(hipGetLastError());
-        launch_cut_finish(b, (int)std::min<uint64_t>((cap_recs + 3) / 4, 1024), stream);
+        launch_pieces(b, c->groups_max, st);
         SIFT_HIP(hipGetLastError());
     }
-    if (d_tmp) SIFT_HIP(hipFreeAsync(d_tmp, stream));
+    if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, st));
     return SIFT_OK;
 }
 
@@ -797,7 +923,8 @@ int sift_chunk_crc_device(int device, const void* d_type_and_data, uint64_t data
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    uint32_t* ws = workspace ? static_cast<uint32_t*>(workspace) : ring_slot(c);
+    uint32_t* ws = static_cast<uint32_t*>(workspace);
+    if (!ws && (rc = stream_workspace(c, static_cast<hipStream_t>(stream), &ws)) != SIFT_OK) return rc;
     // container.rs:80-83: new() -> update(type) -> update(data) -> finalize().
     // Two updates over adjacent bytes equal one update over their concatenation.
     return launch_compute(c, SIFT_CRC_INIT, nullptr, d_type_and_data, data_len + 4u, 0xFFFFFFFFu,

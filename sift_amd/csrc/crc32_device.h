@@ -118,28 +118,34 @@ constexpr uint32_t kMaxLevel = 14;
 constexpr uint32_t kVoidSlot = 0xFFFFFFFFu;  // piece_rec entry of a reservation that did not fit           // pieces of at most 1 GiB (32-bit buffer offsets)
 
 struct CutRecord {
-    uint64_t span_off;    // first byte of the CRC span, from BatchArgs::base
+    uint64_t span_off;           // first byte of the CRC span, from BatchArgs::base
     uint64_t span_len;
-    uint32_t item;        // index into out / data_len
-    uint32_t piece_base;  // its pieces are piece_base .. piece_base + np
-    uint32_t np;
+    unsigned long long acc;      // XOR of the weighted residues of the runs that have arrived
+    unsigned long long arrived;  // pieces those runs covered; the run that brings it to np finishes the item
+    uint32_t item;               // index into out / data_len
+    uint32_t piece_base;         // its pieces are piece_base .. piece_base + np
+    uint32_t np;                 // 0: voided reservation
     uint32_t level;
-    uint32_t cont;        // status the item gets if the span's CRC matches (verify modes)
-    uint32_t dlen;        // verify modes: data length of the chunk
+    uint32_t cont;               // status the item gets if the span's CRC matches (verify modes)
+    uint32_t dlen;               // verify modes: data length of the chunk
     uint32_t pad[2];
 };
-static_assert(sizeof(CutRecord) == 48, "CutRecord layout");
+static_assert(sizeof(CutRecord) == 64, "CutRecord layout");
 
+// Scratch of one batch call.  The three counters sit at the head of the scratch
+// block, are zero between calls, and are put back to zero by the piece kernel's
+// last workgroup to leave.
 struct CutArgs {
     uint32_t* counts;            // records filed (may run past cap_recs); null = never cut
+    uint32_t* left;              // piece-kernel workgroups that have left
     unsigned long long* pieces;  // piece slots reserved (may run past cap_pieces)
     CutRecord* recs;
-    uint32_t* piece_rec;         // piece -> record slot
-    uint32_t* piece_res;         // piece -> residue, weighted to the end of its span's body
+    uint32_t* piece_rec;         // piece -> record slot, or kVoidSlot
     uint32_t cap_recs, cap_pieces;
     uint32_t wave_max;           // spans of up to this many bytes stay on the wave that found them
     uint32_t piece_min_log2;     // smallest piece, log2 bytes (kPieceMinLog2 unless tuned)
 };
+constexpr size_t kCutHeadBytes = 256;  // counts @0, left @64, pieces @128
 
 // Batch kernel (one wave per buffer).  Buffer i is `lens[i]` bytes at
 // `base + offsets[i]`.  In the verify / write modes the item is a serialized
@@ -165,7 +171,6 @@ struct BatchArgs {
 
 void launch_batch(const BatchArgs& b, int groups, void* stream);
 void launch_pieces(const BatchArgs& b, int groups, void* stream);
-void launch_cut_finish(const BatchArgs& b, int groups, void* stream);
 void launch_clear(uint32_t* words, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);

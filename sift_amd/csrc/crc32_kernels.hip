@@ -538,6 +538,8 @@ __device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, con
         r.level = level;
         r.cont = cont;
         r.dlen = dlen;
+        r.acc = 0ull;
+        r.arrived = 0ull;
         r.pad[0] = r.pad[1] = 0u;
         c.recs[slot] = r;
     }
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 }
 
 // ---------------------------------------------------------------------------
-// Piece kernel: the pieces the batch kernel filed, ONE WORKGROUP PER PIECE, with
+// Piece kernel: the pieces the batch kernel filed, one workgroup per piece, with
 // the tile kernel's algorithm (16 KiB tiles, stride-one-tile Horner, y table
 // replicated per bank).  Piece j of a record covers
 //     [Eb - (np-j)*P, Eb - (np-1-j)*P),   Eb = end of the span rounded down to 16,
@@ -709,8 +711,51 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 // Pieces are small (64 KiB) so that one long item alone still spreads over the
 // chip; when the list is long the kernel, which knows its length, regroups:
 // neighbouring pieces of one record are adjacent in memory, so a run of them
-// inside a window is streamed as ONE longer piece (its residue stored for the
-// run's last piece, zero for the others).
+// inside a window is streamed as ONE longer piece.
+//
+// A run's weighted residue is XORed into its record's accumulator and the run's
+// piece count added to the record's arrival count, the same two-atomic exchange
+// as the tile kernel's; the run whose add brings the count to np has seen every
+// other run's XOR performed, swaps the accumulator out, walks the < 16 tail bytes
+// and gives the item its verdict (what the batch kernel does after a wave_crc).
+namespace {
+
+// One lane.  `r` is the register at the end of the span's body.
+__device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecord* rp, uint32_t r) {
+    const uint8_t* end = b.base + rp->span_off + rp->span_len;
+    const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
+    for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
+    const uint32_t item = rp->item;
+    if (!b.verify) {
+        b.out[item] = r ^ b.xor_out;
+        return;
+    }
+    const uint32_t crc = r ^ 0xFFFFFFFFu;  // container.rs:83
+    uint32_t status;
+    if (b.verify == 3) {
+        uint8_t* slot = const_cast<uint8_t*>(end);  // Chunk::write: the crc goes behind the data, :75
+        for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
+        status = 0;
+    } else {
+        status = crc == be32(end) ? rp->cont : 5u;  // container.rs:60-63, then what follows
+    }
+    b.out[item] = status;
+    if (b.data_len) b.data_len[item] = status == 0 ? rp->dlen : 0u;
+}
+
+// A workgroup of the piece kernel leaves: the last one out puts the call's
+// counters back to zero for the next call on this scratch block.
+__device__ __forceinline__ void leave_pieces(const CutArgs& c, uint32_t groups) {
+    const uint32_t t = __hip_atomic_fetch_add(c.left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == groups - 1u) {
+        __hip_atomic_exchange(c.counts, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(c.pieces, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(c.left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace
+
 __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     constexpr int kZWords = 32 * 32;
     __shared__ uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves];
@@ -722,12 +767,15 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     const CutArgs& c = b.cut;
     const unsigned long long reserved = *c.pieces;
     const uint32_t total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
-    // window: about four per workgroup once the list is long enough, at most 64 pieces
-    uint32_t g = total / (gridDim.x * 4u);
+    // window: about two per workgroup once the list is long enough, at most 64 pieces
+    uint32_t g = total / (gridDim.x * 2u);
     g = g < 1u ? 1u : (g > 64u ? 64u : g);
-    if ((uint64_t)blockIdx.x * g >= total) return;
-
     const uint32_t tid = threadIdx.x;
+    if ((uint64_t)blockIdx.x * g >= total) {
+        if (tid == 0) leave_pieces(c, gridDim.x);
+        return;
+    }
+
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
     const uint32_t row32 = tid & 31u;
 #pragma unroll 16
@@ -845,57 +893,25 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
             uint32_t k = np - 1u - jl;
             for (uint32_t bit = 0; k; ++bit, k >>= 1)
                 if (k & 1u) x = mul_rows(x, ldsZ[((3u + plog + bit) & 31u) * 32u + row32], row32);
-            if (tid < run) c.piece_res[p + tid] = tid == run - 1u ? x : 0u;
+            if (tid == 0) {
+                // 8-byte agent-scope atomics on both sides (see crc32_tiles_kernel): the
+                // XOR has been performed at the memory side before the add issues.
+                CutRecord* rw = c.recs + slot;
+                unsigned long long old =
+                    __hip_atomic_fetch_xor(&rw->acc, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+                const unsigned long long before =
+                    __hip_atomic_fetch_add(&rw->arrived, (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + run == (unsigned long long)np) {
+                    const unsigned long long v =
+                        __hip_atomic_exchange(&rw->acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finish_record(b, rp, (uint32_t)v);
+                }
+            }
         }
         p += run;
     }
-}
-
-// Finisher: one wave per filed record.  XORs the record's weighted residues (the
-// register at the end of the span's body), walks the < 16 tail bytes, and does
-// what the batch kernel does after a wave_crc, per mode.
-__global__ __launch_bounds__(256) void crc32_cut_finish_kernel(BatchArgs b) {
-    const CutArgs& c = b.cut;
-    const uint32_t filed = *c.counts;
-    const uint32_t nrec = filed < c.cap_recs ? filed : c.cap_recs;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * 4u;
-    for (uint32_t s = wave; s < nrec; s += nwaves) {
-        const CutRecord* rp = c.recs + s;
-        const uint32_t np = rp->np, pbase = rp->piece_base;
-        if (np == 0) continue;  // voided reservation
-        uint32_t r = 0;
-        for (uint32_t t = lane; t < np; t += 256u) {
-            const uint32_t r0 = c.piece_res[pbase + t];
-            const uint32_t r1 = t + 64u < np ? c.piece_res[pbase + t + 64u] : 0u;
-            const uint32_t r2 = t + 128u < np ? c.piece_res[pbase + t + 128u] : 0u;
-            const uint32_t r3 = t + 192u < np ? c.piece_res[pbase + t + 192u] : 0u;
-            r ^= r0 ^ r1 ^ r2 ^ r3;
-        }
-        r = wave_xor(r);
-        if (lane != 0) continue;
-        const uint8_t* span = b.base + rp->span_off;
-        const uint8_t* end = span + rp->span_len;
-        const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
-        for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
-        const uint32_t item = rp->item;
-        if (!b.verify) {
-            b.out[item] = r ^ b.xor_out;
-            continue;
-        }
-        const uint32_t crc = r ^ 0xFFFFFFFFu;  // container.rs:83
-        uint32_t status;
-        if (b.verify == 3) {
-            uint8_t* slot = const_cast<uint8_t*>(end);
-            for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
-            status = 0;
-        } else {
-            status = crc == be32(end) ? rp->cont : 5u;  // container.rs:60-63, then what follows
-        }
-        b.out[item] = status;
-        if (b.data_len) b.data_len[item] = status == 0 ? rp->dlen : 0u;
-    }
+    if (tid == 0) leave_pieces(c, gridDim.x);
 }
 
 // Zeroes 64 words (two 128-B lines) of a workspace.
@@ -912,11 +928,6 @@ void launch_batch(const BatchArgs& b, int groups, void* stream) {
 
 void launch_pieces(const BatchArgs& b, int groups, void* stream) {
     hipLaunchKernelGGL(crc32_pieces_kernel, dim3(groups), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), b);
-}
-
-void launch_cut_finish(const BatchArgs& b, int groups, void* stream) {
-    hipLaunchKernelGGL(crc32_cut_finish_kernel, dim3(groups), dim3(256), 0,
                        static_cast<hipStream_t>(stream), b);
 }
 

@@ -65,12 +65,16 @@ def test_large_chunk_and_errors(gpu, oracle):
         with pytest.raises(container.Error) as e:
             container.read_chunk(bytes(bad))
         assert e.value.kind == "ReadCrcMismatch", where
-    # flipped length byte: the chunk no longer fits -> Read
-    bad = bytearray(ser)
-    bad[2] ^= 0x01
-    with pytest.raises(container.Error) as e:
-        container.read_chunk(bytes(bad))
-    assert e.value.kind in ("Read", "ReadCrcMismatch")
+    # flipped length byte: the verdict is whatever Chunk::read gives on the same bytes
+    kinds = {1: "Read", 3: "ReadInvalidChunkSize", 5: "ReadCrcMismatch"}
+    for where, bit in ((2, 0x01), (3, 0x01), (0, 0x40), (1, 0x80)):
+        bad = bytearray(ser)
+        bad[where] ^= bit
+        want = oracle.read_chunk(bytes(bad))[0]
+        assert want in kinds
+        with pytest.raises(container.Error) as e:
+            container.read_chunk(bytes(bad))
+        assert e.value.kind == kinds[want], (where, bit)
     with pytest.raises(container.Error) as e:
         container.read_chunk(struct.pack(">I", (1 << 30) + 1) + b"AMRG")
     assert e.value.kind == "ReadInvalidChunkSize"

@@ -262,6 +262,45 @@ def test_two_threads_two_streams(gpu, oracle):
     assert not errors, errors
 
 
+def test_null_workspace_many_streams_in_flight(gpu, oracle):
+    # workspace=NULL: the library keeps one workspace per stream, so calls in flight
+    # on different streams never share an accumulator, however many there are.
+    # 8 streams x 200 calls, nothing synchronised until the end.
+    nstreams, ncalls = 8, 200
+    bufs = [_rand((3 << 20) + 4099 * i + 1, seed=60 + i) for i in range(nstreams)]
+    want = [oracle.compute(0xFFFFFFFF, b) for b in bufs]
+    dbufs = [torch.from_numpy(b).cuda() for b in bufs]
+    outs = [torch.zeros(ncalls, dtype=torch.int32, device="cuda") for _ in range(nstreams)]
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    torch.cuda.synchronize()
+    for k in range(ncalls):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                gpu.compute_async(0xFFFFFFFF, dbufs[i], outs[i][k:k + 1])   # no workspace
+    torch.cuda.synchronize()
+    for i in range(nstreams):
+        got = {int(v) & 0xFFFFFFFF for v in outs[i].cpu().tolist()}
+        assert got == {want[i]}, (i, [hex(g) for g in got], hex(want[i]))
+
+
+def test_null_workspace_is_refused_under_capture_and_reset_works(gpu, oracle):
+    from sift_amd import _lib
+    buf = _rand((2 << 20) + 5, seed=77)
+    d = torch.from_numpy(buf).cuda()
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.compute_async(0xFFFFFFFF, d, out)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        with pytest.raises(_lib.SiftError) as e:
+            gpu.compute_async(0xFFFFFFFF, d, out)          # library scratch cannot go into a graph
+        ws = None
+    assert e.value.status == _lib.ERR_INVALID_ARG and "captured" in str(e.value)
+    del graph
+    _lib.check(_lib.lib.sift_reset_workspace(0))
+    assert gpu.compute(0xFFFFFFFF, d) == oracle.compute(0xFFFFFFFF, buf)
+
+
 def test_random_differential(gpu):
     # 400 random (offset, length, state) triples across every geometry the host
     # picks (1..256 groups, 1..10 tiles per group, ragged first tiles, tails),

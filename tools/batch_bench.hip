@@ -61,11 +61,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_len, 8ull << 20));
     std::vector<uint64_t> off(1 << 20), len(1 << 20);
 
+    // batch_bench chunk <bytes>: only Chunk::read on one chunk of that many data bytes (for rocprofv3)
+    const bool only_chunk = argc >= 3 && !strcmp(argv[1], "chunk");
+    const size_t only_n = only_chunk ? strtoull(argv[2], nullptr, 0) : 0;
     printf("{\"rows\": [\n");
     bool first = true;
     // plain buffers back to back in the blob, descriptors in HBM and on the host
     const size_t sizes[] = {64, 1024, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
     for (size_t size : sizes) {
+        if (only_chunk) break;
         const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
         for (uint32_t i = 0; i < n; ++i) {
             off[i] = (uint64_t)i * size;
@@ -101,6 +105,7 @@ int main(int argc, char** argv) {
     }
     // Chunk::read on ONE serialized chunk: length only in its header
     for (size_t n : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20, ((size_t)1 << 30) - 16}) {
+        if (only_chunk && n != only_n) continue;
         uint8_t hdr[8] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n, 'A', 'M', 'R', 'G'};
         CK(hipMemcpy(blob, hdr, 8, hipMemcpyHostToDevice));
         uint32_t crc = 0;
@@ -129,11 +134,12 @@ int main(int argc, char** argv) {
         const double t_wall = now() - t0;
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        printf(",\n {\"kind\": \"read_one_chunk\", \"descriptors\": \"device\", \"chunk_data_bytes\": %zu, "
+        printf("%s {\"kind\": \"read_one_chunk\", \"descriptors\": \"device\", \"chunk_data_bytes\": %zu, "
                "\"issue_us_per_call\": %.2f, \"wall_us_per_call\": %.2f, \"device_us_per_call\": %.2f, "
                "\"GBps_wall\": %.1f, \"GBps_device\": %.1f}",
-               n, t_issue / reps * 1e6, t_wall / reps * 1e6, ms * 1e3 / reps, (double)(n + 4) / (t_wall / reps) / 1e9,
+               first ? "" : ",\n", n, t_issue / reps * 1e6, t_wall / reps * 1e6, ms * 1e3 / reps, (double)(n + 4) / (t_wall / reps) / 1e9,
                (double)(n + 4) / (ms * 1e-3 / reps) / 1e9);
+        first = false;
         fflush(stdout);
     }
     printf("\n]}\n");
