@@ -790,6 +790,46 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));
     __syncthreads();
 
+    // Wave 0 hands residues to their records through a three-stage pipeline, so
+    // that it never waits for an atomic it has just issued (the other 15 waves
+    // would wait for it at the next run's barrier):
+    //   cur      residues of consecutive runs of ONE record, summed in a register
+    //   stage 1  record whose XOR into `acc` has been issued
+    //   stage 2  record whose `arrived` add has been issued (after stage 1's XOR
+    //            returned: 8-byte agent-scope atomics on both sides, the XOR
+    //            performed at the memory side before the add issues, as in
+    //            crc32_tiles_kernel); when the add returns np - count, this was
+    //            the record's last commit and lane 0 finishes the item.
+    // The pipeline moves one step each time the workgroup changes record, a whole
+    // run after the previous step, by which time the awaited atomic has long returned.
+    uint32_t cur_slot = kVoidSlot, cur_x = 0, cur_cnt = 0;
+    uint32_t s1_slot = kVoidSlot, s1_cnt = 0, s2_slot = kVoidSlot, s2_cnt = 0;
+    unsigned long long s1_old = 0, s2_before = 0;
+#define SIFT_COMMIT_ADVANCE()                                                                         \
+    do {                                                                                              \
+        if (s2_slot != kVoidSlot && tid == 0) {                                                       \
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(s2_before) : "memory");                           \
+            CutRecord* r2_ = c.recs + s2_slot;                                                        \
+            if (s2_before + s2_cnt == (unsigned long long)r2_->np) {                                  \
+                const unsigned long long v_ =                                                         \
+                    __hip_atomic_exchange(&r2_->acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                finish_record(b, r2_, (uint32_t)v_);                                                  \
+            }                                                                                         \
+        }                                                                                             \
+        s2_slot = s1_slot;                                                                            \
+        s2_cnt = s1_cnt;                                                                              \
+        if (s1_slot != kVoidSlot && tid == 0) {                                                       \
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(s1_old) : "memory");                              \
+            s2_before = __hip_atomic_fetch_add(&c.recs[s1_slot].arrived, (unsigned long long)s1_cnt,  \
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+        }                                                                                             \
+        s1_slot = cur_slot;                                                                           \
+        s1_cnt = cur_cnt;                                                                             \
+        if (cur_slot != kVoidSlot && tid == 0)                                                        \
+            s1_old = __hip_atomic_fetch_xor(&c.recs[cur_slot].acc, (unsigned long long)cur_x,         \
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+    } while (0)
+
     const uint32_t start_state = b.verify ? 0xFFFFFFFFu : b.state;
     uint32_t parity = 0;
     uint64_t w = blockIdx.x;  // window index: this workgroup takes w, w + grid, ...
@@ -893,24 +933,26 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
             uint32_t k = np - 1u - jl;
             for (uint32_t bit = 0; k; ++bit, k >>= 1)
                 if (k & 1u) x = mul_rows(x, ldsZ[((3u + plog + bit) & 31u) * 32u + row32], row32);
-            if (tid == 0) {
-                // 8-byte agent-scope atomics on both sides (see crc32_tiles_kernel): the
-                // XOR has been performed at the memory side before the add issues.
-                CutRecord* rw = c.recs + slot;
-                unsigned long long old =
-                    __hip_atomic_fetch_xor(&rw->acc, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
-                const unsigned long long before =
-                    __hip_atomic_fetch_add(&rw->arrived, (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + run == (unsigned long long)np) {
-                    const unsigned long long v =
-                        __hip_atomic_exchange(&rw->acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    finish_record(b, rp, (uint32_t)v);
-                }
+            // into the record, through wave 0's commit pipeline
+            if (slot == cur_slot) {
+                cur_x ^= x;
+                cur_cnt += run;
+            } else {
+                SIFT_COMMIT_ADVANCE();
+                cur_slot = slot;
+                cur_x = x;
+                cur_cnt = run;
             }
         }
         p += run;
     }
+    if (tid < 64u) {  // drain the pipeline: three stages
+        SIFT_COMMIT_ADVANCE();
+        cur_slot = kVoidSlot;
+        SIFT_COMMIT_ADVANCE();
+        SIFT_COMMIT_ADVANCE();
+    }
+#undef SIFT_COMMIT_ADVANCE
     if (tid == 0) leave_pieces(c, gridDim.x);
 }
 
