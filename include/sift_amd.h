@@ -97,7 +97,9 @@ enum {
                                     device; 0: one wave per item whatever its length */
     SIFT_TUNE_BATCH_WAVE_MAX = 3,/* bytes of CRC span one wave keeps before the item is cut;
                                     0 (default) = 256 KiB for n >= 4096 items, else 32 KiB */
-    SIFT_TUNE_BATCH_PIECE_LOG2 = 4 /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
+    SIFT_TUNE_BATCH_PIECE_LOG2 = 4, /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
+    SIFT_TUNE_BATCH_PLAN = 5     /* 1 (default): up to 64 items (not whole documents) go straight to the
+                                    piece kernel, which plans them itself; 0: always two launches */
 };
 int sift_tune(int key, int value);
 

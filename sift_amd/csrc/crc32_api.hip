@@ -32,6 +32,7 @@ std::atomic<bool> g_single_launch{true};
 std::atomic<int> g_batch_cut{1};          // 0: every item stays on one wave (round-1 behaviour, A/B only)
 std::atomic<int> g_batch_wave_max{0};     // bytes a single wave keeps; 0 = chosen from n (run_batch)
 std::atomic<int> g_batch_piece_log2{kPieceMinLog2};
+std::atomic<int> g_batch_plan{1};         // 0: always file through the wave kernel, even for few items
 
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -49,6 +50,10 @@ int fail_hip(hipError_t e, const char* what) {
 constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32 words on
 constexpr size_t kSlotWords = kMaxGroups + 96;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
+// A stream's small scratch block: compute workspace | accumulators of the piece
+// kernel's self-planned form (kPlanMax records), all zero between calls.
+constexpr size_t kPlanRecsOffset = (kSlotWords * sizeof(uint32_t) + 255) / 256 * 256;
+constexpr size_t kStreamBlockBytes = kPlanRecsOffset + kPlanMax * sizeof(CutRecord);
 
 // Scratch of sift_crc32_compute_device_static, the entry point that allocates
 // nothing: one workspace slot in the code object's own device memory.  Each GPU
@@ -380,7 +385,25 @@ bool capturing(hipStream_t stream) {
     return st != hipStreamCaptureStatusNone;
 }
 
-// The compute workspace of `stream` (created zeroed on the stream's first call).
+// The small scratch block of `stream` (created zeroed on the stream's first
+// call).  c->scratch_mutex is held.
+int stream_block_locked(DeviceCtx* c, hipStream_t stream, uint8_t** blk) {
+    StreamScratch& ss = c->per_stream[stream];
+    if (!ss.compute_ws) {
+        uint32_t* p = nullptr;
+        SIFT_HIP(hipMalloc(&p, kStreamBlockBytes));
+        hipError_t e = hipMemset(p, 0, kStreamBlockBytes);  // synchronous: done before any launch
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail_hip(e, "hipMemset(workspace)");
+        }
+        ss.compute_ws = p;
+    }
+    *blk = reinterpret_cast<uint8_t*>(ss.compute_ws);
+    return SIFT_OK;
+}
+
+// The compute workspace of `stream`.
 int stream_workspace(DeviceCtx* c, hipStream_t stream, uint32_t** ws) {
     if (capturing(stream)) {
         g_last_error = "stream is being captured: pass a workspace of sift_crc32_workspace_bytes(), or use "
@@ -388,18 +411,10 @@ int stream_workspace(DeviceCtx* c, hipStream_t stream, uint32_t** ws) {
         return SIFT_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lock(c->scratch_mutex);
-    StreamScratch& ss = c->per_stream[stream];
-    if (!ss.compute_ws) {
-        uint32_t* p = nullptr;
-        SIFT_HIP(hipMalloc(&p, kSlotWords * sizeof(uint32_t)));
-        hipError_t e = hipMemset(p, 0, kSlotWords * sizeof(uint32_t));  // synchronous: done before any launch
-        if (e != hipSuccess) {
-            (void)hipFree(p);
-            return fail_hip(e, "hipMemset(workspace)");
-        }
-        ss.compute_ws = p;
-    }
-    *ws = ss.compute_ws;
+    uint8_t* blk = nullptr;
+    const int rc = stream_block_locked(c, stream, &blk);
+    if (rc != SIFT_OK) return rc;
+    *ws = reinterpret_cast<uint32_t*>(blk);
     return SIFT_OK;
 }
 
@@ -468,7 +483,7 @@ int sift_reset_workspace(int device) {
     SIFT_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lock(c->scratch_mutex);
     for (auto& kv : c->per_stream) {
-        if (kv.second.compute_ws) SIFT_HIP(hipMemset(kv.second.compute_ws, 0, kSlotWords * sizeof(uint32_t)));
+        if (kv.second.compute_ws) SIFT_HIP(hipMemset(kv.second.compute_ws, 0, kStreamBlockBytes));
         if (kv.second.batch) SIFT_HIP(hipMemset(kv.second.batch, 0, kCutHeadBytes));
     }
     SIFT_HIP(hipMemset(c->static_scratch, 0, kStaticScratchWords * sizeof(uint32_t)));
@@ -527,6 +542,9 @@ int sift_tune(int key, int value) {
             return SIFT_OK;
         case SIFT_TUNE_BATCH_CUT:
             g_batch_cut = value != 0;
+            return SIFT_OK;
+        case SIFT_TUNE_BATCH_PLAN:
+            g_batch_plan = value != 0;
             return SIFT_OK;
         case SIFT_TUNE_BATCH_WAVE_MAX:
             if (value != 0 && value < 4096) break;
@@ -829,7 +847,17 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // One batch call at a time issues its launch sequence per device: the scratch
     // block of a stream is shared by that stream's calls in stream order.
     std::lock_guard<std::mutex> lock(c->scratch_mutex);
-    if (cut) {
+    // Few items (and not the document mode, whose second chunk needs the wave
+    // kernel): no filing pass, the piece kernel plans for itself.
+    const bool plan = cut && n <= kPlanMax && verify != 2 && g_batch_plan.load() != 0;
+    if (plan) {
+        uint8_t* blk = nullptr;
+        rc = stream_block_locked(c, st, &blk);
+        if (rc != SIFT_OK) return rc;
+        b.cut.recs = reinterpret_cast<CutRecord*>(blk + kPlanRecsOffset);
+        b.cut.wave_max = wave_max;
+        b.cut.piece_min_log2 = (uint32_t)piece_log2;
+    } else if (cut) {
         StreamScratch& ss = c->per_stream[st];
         const size_t need = kCutHeadBytes + sizeof(CutRecord) * cap_recs + 4 * cap_pieces;
         if (ss.batch_bytes < need) {
@@ -873,11 +901,16 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     const int waves_per_group = kThreads / 64;
     const int groups = (int)std::min<uint64_t>(((uint64_t)n + waves_per_group - 1) / waves_per_group,
                                                (uint64_t)c->groups_max);
-    launch_batch(b, groups, st);
-    SIFT_HIP(hipGetLastError());
-    if (cut) {
-        launch_pieces(b, c->groups_max, st);
+    if (plan) {
+        launch_pieces(b, c->groups_max, true, st);
         SIFT_HIP(hipGetLastError());
+    } else {
+        launch_batch(b, groups, st);
+        SIFT_HIP(hipGetLastError());
+        if (cut) {
+            launch_pieces(b, c->groups_max, false, st);
+            SIFT_HIP(hipGetLastError());
+        }
     }
     if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, st));
     return SIFT_OK;

@@ -115,6 +115,7 @@ struct CombineMats {
 constexpr int kPieceMinLog2 = 16;            // 64 KiB: four 16 KiB tiles
 constexpr uint32_t kMaxPiecesPerItem = 1024; // level is raised until np fits (up to kMaxLevel)
 constexpr uint32_t kMaxLevel = 14;
+constexpr uint32_t kPlanMax = 64;             // up to this many items the piece kernel plans for itself (one lane each)
 constexpr uint32_t kVoidSlot = 0xFFFFFFFFu;  // piece_rec entry of a reservation that did not fit           // pieces of at most 1 GiB (32-bit buffer offsets)
 
 struct CutRecord {
@@ -170,7 +171,7 @@ struct BatchArgs {
 };
 
 void launch_batch(const BatchArgs& b, int groups, void* stream);
-void launch_pieces(const BatchArgs& b, int groups, void* stream);
+void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream);
 void launch_clear(uint32_t* words, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);

@@ -489,6 +489,15 @@ __device__ __forceinline__ uint32_t mul_rows(uint32_t x, uint32_t row, uint32_t 
     return t;
 }
 
+// Level and piece count of a span whose whole vectors cover `body` bytes.
+__device__ __forceinline__ uint32_t span_level(uint64_t body, uint32_t piece_min_log2) {
+    uint32_t level = 0;
+    while (level < kMaxLevel - (piece_min_log2 - (uint32_t)kPieceMinLog2) &&
+           (body >> (piece_min_log2 + level)) >= (uint64_t)kMaxPiecesPerItem)
+        ++level;
+    return level;
+}
+
 // A wave that meets a long CRC span files it for the piece kernel instead of
 // walking it.  Wave-uniform.  Returns false (nothing changed) when cutting is off,
 // the span is short, or the record / piece arrays are full: the caller then
@@ -500,10 +509,7 @@ __device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, con
     if (!c.counts || len <= (uint64_t)c.wave_max) return false;
     const uint64_t A = reinterpret_cast<uint64_t>(ptr);
     const uint64_t body = ((A + len) & ~15ull) - (A & ~15ull);  // whole vectors, > 0 here
-    uint32_t level = 0;
-    while (level < kMaxLevel - (c.piece_min_log2 - (uint32_t)kPieceMinLog2) &&
-           (body >> (c.piece_min_log2 + level)) >= (uint64_t)kMaxPiecesPerItem)
-        ++level;
+    const uint32_t level = span_level(body, c.piece_min_log2);
     const uint32_t plog = c.piece_min_log2 + level;
     const uint64_t np64 = (body + (1ull << plog) - 1) >> plog;
     if (np64 > 0x40000000ull) return false;
@@ -720,11 +726,10 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 // and gives the item its verdict (what the batch kernel does after a wave_crc).
 namespace {
 
-// One lane.  `r` is the register at the end of the span's body.
-__device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecord* rp, uint32_t r) {
+// One lane.  `r` is the register over the whole span: what the batch kernel does
+// after a wave_crc, per mode.
+__device__ __forceinline__ void verdict_record(const BatchArgs& b, const CutRecord* rp, uint32_t r) {
     const uint8_t* end = b.base + rp->span_off + rp->span_len;
-    const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
-    for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
     const uint32_t item = rp->item;
     if (!b.verify) {
         b.out[item] = r ^ b.xor_out;
@@ -743,6 +748,106 @@ __device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecor
     if (b.data_len) b.data_len[item] = status == 0 ? rp->dlen : 0u;
 }
 
+// One lane.  `r` is the register at the end of the span's body: the < 16 tail
+// bytes, then the verdict.
+__device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecord* rp, uint32_t r) {
+    const uint8_t* end = b.base + rp->span_off + rp->span_len;
+    const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
+    for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
+    verdict_record(b, rp, r);
+}
+
+// Few items (n <= kPlanMax, not the document mode): no filing pass.  Every
+// workgroup of the piece kernel works the plan out for itself, identically: lane
+// i of wave 0 reads item i's descriptor (and chunk header), runs the checks that
+// come before the CRC, and turns its span into np pieces; a wave scan gives the
+// piece bases.  The plan lands in LDS as CutRecords.  Items that end without a
+// span to stream (an error before the CRC, or a span under 32 bytes, walked by
+// the lane) get their verdict from workgroup 0 alone.  Returns the piece total.
+__device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, CutRecord* prec, uint32_t* pbase_lds,
+                                               uint32_t* total_lds) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64u) {
+        const uint32_t i = tid;
+        uint32_t np = 0, level = 0, dlen = 0;
+        uint64_t span_off = 0, span_len = 0;
+        if (i < b.n) {
+            const uint64_t off = b.offsets[i], avail = b.lens[i];
+            const uint8_t* ptr = b.base + off;
+            uint32_t status = 0;
+            bool pending = true;
+            if (!b.verify) {
+                span_off = off;
+                span_len = avail;
+            } else {
+                if (b.verify == 1) {
+                    status = read_chunk_head(ptr, avail, b.chunk_limit, &dlen);  // container.rs:48-60
+                } else {  // 3: Chunk::write's crc step, avail = bytes of the slot
+                    if (avail < 12u) {
+                        status = 2;
+                    } else {
+                        dlen = be32(ptr);
+                        if (avail < 12ull + (uint64_t)dlen) status = 2;
+                    }
+                }
+                span_off = off + 4u;
+                span_len = 4ull + dlen;
+                if (status) {
+                    pending = false;
+                    if (blockIdx.x == 0) {
+                        b.out[i] = status;
+                        if (b.data_len) b.data_len[i] = 0u;
+                    }
+                }
+            }
+            CutRecord r;
+            r.span_off = span_off;
+            r.span_len = span_len;
+            r.acc = r.arrived = 0ull;
+            r.item = i;
+            r.cont = 0u;
+            r.dlen = dlen;
+            r.pad[0] = r.pad[1] = 0u;
+            if (pending && span_len < 32u) {
+                // too short to carry the state inside whole vectors: one lane walks it
+                if (blockIdx.x == 0) {
+                    uint32_t reg = b.verify ? 0xFFFFFFFFu : b.state;
+                    const uint8_t* sp = b.base + span_off;
+                    for (uint32_t k = 0; k < (uint32_t)span_len; ++k) reg = crc_step_byte(reg, sp[k]);
+                    r.piece_base = r.np = r.level = 0u;
+                    verdict_record(b, &r, reg);
+                }
+                pending = false;
+            }
+            if (pending) {
+                const uint64_t A = reinterpret_cast<uint64_t>(b.base) + span_off;
+                const uint64_t body = ((A + span_len) & ~15ull) - (A & ~15ull);
+                level = span_level(body, b.cut.piece_min_log2);
+                const uint32_t plog = b.cut.piece_min_log2 + level;
+                np = (uint32_t)((body + (1ull << plog) - 1) >> plog);
+            }
+            r.np = np;
+            r.level = level;
+            // exclusive scan of np over the lanes below n (a lane only reads lower lanes,
+            // all of which are in this branch)
+            uint32_t incl = np;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if ((int)tid >= d) incl += up;
+            }
+            r.piece_base = incl - np;
+            prec[i] = r;
+            pbase_lds[i] = r.piece_base;
+            if (i == b.n - 1u) *total_lds = incl;
+        } else {
+            pbase_lds[i] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    return *total_lds;
+}
+
 // A workgroup of the piece kernel leaves: the last one out puts the call's
 // counters back to zero for the next call on this scratch block.
 __device__ __forceinline__ void leave_pieces(const CutArgs& c, uint32_t groups) {
@@ -756,23 +861,36 @@ __device__ __forceinline__ void leave_pieces(const CutArgs& c, uint32_t groups) 
 
 }  // namespace
 
+// PLAN = false: the piece list was filed by crc32_batch_kernel (c.recs, c.piece_rec).
+// PLAN = true:  few items; every workgroup plans them itself (plan_items), the
+//               records are in LDS and only their accumulators (c.recs[i].acc /
+//               .arrived, zero between calls) in device memory.
+template <bool PLAN>
 __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     constexpr int kZWords = 32 * 32;
-    __shared__ uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves];
+    constexpr int kPlanWords = PLAN ? (int)(kPlanMax * sizeof(CutRecord) / 4 + kPlanMax + 16) : 0;
+    __shared__ __align__(16) uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves + kPlanWords];
     uint32_t* ldsY = lds;
     uint32_t* ldsX = lds + kYWords;
     uint32_t* ldsZ = ldsX + kXWords;
     uint32_t* red = ldsZ + kZWords;
+    CutRecord* prec = reinterpret_cast<CutRecord*>(red + 2 * kWaves);  // PLAN only
+    uint32_t* plan_pbase = reinterpret_cast<uint32_t*>(prec + kPlanMax);
 
     const CutArgs& c = b.cut;
-    const unsigned long long reserved = *c.pieces;
-    const uint32_t total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
+    const uint32_t tid = threadIdx.x;
+    uint32_t total;
+    if (PLAN) {
+        total = plan_items(b, prec, plan_pbase, plan_pbase + kPlanMax);
+    } else {
+        const unsigned long long reserved = *c.pieces;
+        total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
+    }
     // window: about two per workgroup once the list is long enough, at most 64 pieces
     uint32_t g = total / (gridDim.x * 2u);
     g = g < 1u ? 1u : (g > 64u ? 64u : g);
-    const uint32_t tid = threadIdx.x;
     if ((uint64_t)blockIdx.x * g >= total) {
-        if (tid == 0) leave_pieces(c, gridDim.x);
+        if (!PLAN && tid == 0) leave_pieces(c, gridDim.x);
         return;
     }
 
@@ -809,10 +927,13 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     do {                                                                                              \
         if (s2_slot != kVoidSlot && tid == 0) {                                                       \
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(s2_before) : "memory");                           \
-            CutRecord* r2_ = c.recs + s2_slot;                                                        \
+            const CutRecord* r2_ = PLAN ? prec + s2_slot : c.recs + s2_slot;                          \
             if (s2_before + s2_cnt == (unsigned long long)r2_->np) {                                  \
-                const unsigned long long v_ =                                                         \
-                    __hip_atomic_exchange(&r2_->acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                const unsigned long long v_ = __hip_atomic_exchange(                                  \
+                    &c.recs[s2_slot].acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
+                if (PLAN) /* no filing pass re-initialises the record: leave it zero */               \
+                    __hip_atomic_exchange(&c.recs[s2_slot].arrived, 0ull, __ATOMIC_RELAXED,           \
+                                          __HIP_MEMORY_SCOPE_AGENT);                                  \
                 finish_record(b, r2_, (uint32_t)v_);                                                  \
             }                                                                                         \
         }                                                                                             \
@@ -841,12 +962,19 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
             p = (uint32_t)(w * g);
             wend = p + g < total ? p + g : total;
         }
-        const uint32_t slot = c.piece_rec[p];
+        uint32_t slot;
+        if (PLAN) {
+            // the last item whose piece base is <= p (items without pieces share the next one's base)
+            const uint32_t pb = plan_pbase[tid & 63u];
+            slot = 63u - (uint32_t)__builtin_clzll(__ballot(pb <= p));
+        } else {
+            slot = c.piece_rec[p];
+        }
         if (slot == kVoidSlot) {  // reservation that did not fit: its span was walked in place
             ++p;
             continue;
         }
-        const CutRecord* rp = c.recs + slot;
+        const CutRecord* rp = PLAN ? prec + slot : c.recs + slot;
         const uint64_t span_off = rp->span_off, span_len = rp->span_len;
         const uint32_t np = rp->np, j = p - rp->piece_base;
         const uint32_t plog = c.piece_min_log2 + rp->level;
@@ -953,7 +1081,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
         SIFT_COMMIT_ADVANCE();
     }
 #undef SIFT_COMMIT_ADVANCE
-    if (tid == 0) leave_pieces(c, gridDim.x);
+    if (!PLAN && tid == 0) leave_pieces(c, gridDim.x);
 }
 
 // Zeroes 64 words (two 128-B lines) of a workspace.
@@ -968,9 +1096,13 @@ void launch_batch(const BatchArgs& b, int groups, void* stream) {
                        static_cast<hipStream_t>(stream), b);
 }
 
-void launch_pieces(const BatchArgs& b, int groups, void* stream) {
-    hipLaunchKernelGGL(crc32_pieces_kernel, dim3(groups), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), b);
+void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream) {
+    if (plan)
+        hipLaunchKernelGGL(crc32_pieces_kernel<true>, dim3(groups), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), b);
+    else
+        hipLaunchKernelGGL(crc32_pieces_kernel<false>, dim3(groups), dim3(kThreads), 0,
+                           static_cast<hipStream_t>(stream), b);
 }
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,

@@ -27,6 +27,7 @@ def tune(gpu):
     L.check(L.lib.sift_tune(L.TUNE_BATCH_CUT, 1))
     L.check(L.lib.sift_tune(L.TUNE_BATCH_WAVE_MAX, 0))
     L.check(L.lib.sift_tune(L.TUNE_BATCH_PIECE_LOG2, 16))
+    L.check(L.lib.sift_tune(L.TUNE_BATCH_PLAN, 1))
 
 
 def test_cut_crc_mixed_lengths(gpu, tune):
@@ -65,6 +66,36 @@ def test_cut_crc_mixed_lengths(gpu, tune):
     short = [i for i, n in enumerate(lens) if n <= (5 << 20) + 12345]
     got = gpu.compute_batch(M, d, [offs[i] for i in short], [lens[i] for i in short], xor_out=M)
     assert [int(g) for g in got.cpu().numpy().view(np.uint32)] == [want[i] for i in short]
+
+
+def test_few_items_planned_by_the_piece_kernel(gpu, tune):
+    # up to 64 items skip the filing pass: every length class and alignment again,
+    # in batches of 1, 2, 37 and 64 items, against the two-launch form and zlib
+    from sift_amd import _lib as L
+    rng = np.random.default_rng(0x51F7 + 5)
+    blob = rng.integers(0, 256, size=(40 << 20) + 4096, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    P = 65536
+    pool = [0, 1, 5, 31, 32, 33, 47, 48, 1000, 16383, 16384, 16385, 32768, 40000, P - 1, P, P + 1, P + 16,
+            2 * P + 1, 5 * P + 3, (1 << 20) + 1, (3 << 20) + 12345, (30 << 20) + 7] + \
+           [int(x) for x in rng.integers(0, 1 << 20, size=41)]
+    for count in (1, 2, 37, 64):
+        for rep in range(3):
+            lens = [pool[int(k)] for k in rng.integers(0, len(pool), size=count)]
+            if count == 1:
+                lens = [[(30 << 20) + 7, 31, 5 * P + 3][rep]]
+            offs = [int(rng.integers(0, blob.size - n + 1)) for n in lens]
+            for state, xo in ((M, M), (0x1234ABCD, 0)):
+                want = [(zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo for o, n in zip(offs, lens)]
+                tune(L.TUNE_BATCH_PLAN, 1)
+                got = gpu.compute_batch(state, d, _dev(offs), _dev(lens), xor_out=xo).cpu().numpy().view(np.uint32)
+                assert [int(g) for g in got] == want, (count, rep, "planned")
+                got = gpu.compute_batch(state, d, offs, lens, xor_out=xo).cpu().numpy().view(np.uint32)
+                assert [int(g) for g in got] == want, (count, rep, "planned, host descriptors")
+                tune(L.TUNE_BATCH_PLAN, 0)
+                got = gpu.compute_batch(state, d, _dev(offs), _dev(lens), xor_out=xo).cpu().numpy().view(np.uint32)
+                assert [int(g) for g in got] == want, (count, rep, "filed")
 
 
 def test_cut_many_items_threshold(gpu):
@@ -107,8 +138,10 @@ def _chunks_case(oracle, rng, sizes):
     return bytes(stream), offs, avail, kinds
 
 
-def test_cut_read_chunks_vs_oracle(gpu, oracle):
-    from sift_amd import container
+@pytest.mark.parametrize("plan", [1, 0])
+def test_cut_read_chunks_vs_oracle(gpu, oracle, tune, plan):
+    from sift_amd import container, _lib as L
+    tune(L.TUNE_BATCH_PLAN, plan)      # 23 items: planned by the piece kernel, or filed by the wave kernel
     rng = np.random.default_rng(0x51F7 + 2)
     sizes = [0, 17, 32764, 32765, 40000, 65536, 65540, 100000, 131072 - 4, 131072, (1 << 20) + 3,
              (3 << 20) + 1, 5_000_000, (24 << 20) + 11, 70000, 300, 33000, (2 << 20) - 4, 65532, 99999, 50000]
@@ -129,8 +162,10 @@ def test_cut_read_chunks_vs_oracle(gpu, oracle):
         assert dl.cpu().tolist() == want_len
 
 
-def test_cut_write_then_read_large_chunks(gpu, oracle):
-    from sift_amd import container
+@pytest.mark.parametrize("plan", [1, 0])
+def test_cut_write_then_read_large_chunks(gpu, oracle, tune, plan):
+    from sift_amd import container, _lib as L
+    tune(L.TUNE_BATCH_PLAN, plan)
     rng = np.random.default_rng(31)
     blob, want, offs, avail = bytearray(), bytearray(), [], []
     for i, n in enumerate([5, 40000, 65536, (1 << 20) + 7, (9 << 20) + 1, 32764, 32765, 100]):
