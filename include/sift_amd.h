@@ -266,6 +266,36 @@ int64_t sift_read_chunk(int device, const uint8_t *in, size_t avail, uint8_t chu
  * Chunk::expect_type.  SIFT_OK or SIFT_ERR_READ. */
 int sift_expect_type(const uint8_t chunk_type[4], const uint8_t expected[4]);
 
+/* ------------------------------------------- document.rs:53-60 -----------
+ * write_document's framing: header, an AMRG chunk holding `payload` (the bytes
+ * encode_document returned: an automerge document, opaque here), an empty SEND
+ * chunk; both CRCs on the GPU.  Returns bytes written (len + 33) or -SIFT_ERR_*
+ * (the error of the first write that fails, as the reference's `?` chain). */
+int64_t sift_write_document(int device, const uint8_t *payload, uint64_t len, uint8_t *out,
+                            size_t cap);
+
+/* ------------------------------------------- document.rs:62-77 -----------
+ * read_document's framing, in the reference's order: read_header, read_chunk
+ * (CRC verified on the GPU) + expect_type(AMRG), read_chunk + expect_type(SEND).
+ * Returns bytes consumed or -SIFT_ERR_* (SIFT_ERR_READ for bad magic, a short
+ * input or a wrong chunk type; trailing bytes are ignored, as the reference
+ * ignores them).  `*stage` (optional) says how far it got; from
+ * SIFT_DOC_SEND_CHUNK on, *payload_off / *payload_len locate the AMRG payload
+ * inside `in`.  The reference decodes the payload (document.rs:69, automerge,
+ * not part of this library) BEFORE it reads the SEND chunk: a caller that wants
+ * the reference's error precedence decodes first whenever stage >= SEND_CHUNK
+ * and lets a decode error win over the SEND chunk's. */
+enum {
+    SIFT_DOC_HEADER = 0,
+    SIFT_DOC_AMRG_CHUNK = 1,
+    SIFT_DOC_AMRG_TYPE = 2,
+    SIFT_DOC_SEND_CHUNK = 3,
+    SIFT_DOC_SEND_TYPE = 4,
+    SIFT_DOC_DONE = 5
+};
+int64_t sift_read_document(int device, const uint8_t *in, size_t avail, uint64_t *payload_off,
+                           uint32_t *payload_len, int *stage);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,11 @@ def lib():
         L.oracle_read_chunk.restype = C.c_int64
         L.oracle_read_chunk.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        L.oracle_write_document.restype = C.c_int64
+        L.oracle_write_document.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.oracle_read_document.restype = C.c_int64
+        L.oracle_read_document.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.oracle_crc_table.restype = C.POINTER(C.c_uint32)
         _lib = L
     return _lib
@@ -96,3 +101,25 @@ def read_chunk(buf, pos: int = 0):
     if n < 0:
         return int(-n), None, 0, 0, 0
     return 0, t.raw, pos + off.value, ln.value, int(n)
+
+
+def write_document(payload) -> bytes:
+    """document.rs:53-60 around an opaque payload."""
+    p, keep = _ptr(payload)
+    out = C.create_string_buffer(keep.size + 9 + 12 + 12)
+    n = lib().oracle_write_document(p, keep.size, out, len(out))
+    if n < 0:
+        raise ValueError(f"oracle_write_document error {-n}")
+    return out.raw[:n]
+
+
+def read_document(buf):
+    """document.rs:62-77 framing.  Returns (status, stage, payload_off, payload_len, consumed)."""
+    import numpy as np
+    a = np.frombuffer(buf, dtype=np.uint8)
+    off, ln, stage = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    n = lib().oracle_read_document(a.ctypes.data if a.size else None, a.size, C.byref(off), C.byref(ln),
+                                   C.byref(stage))
+    if n < 0:
+        return int(-n), stage.value, off.value, ln.value, 0
+    return 0, stage.value, off.value, ln.value, int(n)

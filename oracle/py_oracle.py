@@ -97,3 +97,24 @@ def read_chunk(buf: bytes, pos: int = 0):
     if crc != chunk_crc(chunk_type, data):
         raise ContainerError("ReadCrcMismatch")
     return chunk_type, data, pos + 12 + length
+
+
+AUTOMERGE_CHUNK = b"AMRG"  # document.rs:50
+END_CHUNK = b"SEND"        # document.rs:51
+
+
+def write_document(payload: bytes) -> bytes:
+    """document.rs:53-60; `payload` stands for encode_document's bytes."""
+    return write_header() + write_chunk(AUTOMERGE_CHUNK, payload) + write_chunk(END_CHUNK, b"")
+
+
+def read_document(buf: bytes) -> bytes:
+    """document.rs:62-77 without decode_document: returns the AMRG payload."""
+    pos = read_header(buf)
+    chunk_type, data, pos = read_chunk(buf, pos)
+    if chunk_type != AUTOMERGE_CHUNK:
+        raise ContainerError("Read")
+    end_type, _, pos = read_chunk(buf, pos)
+    if end_type != END_CHUNK:
+        raise ContainerError("Read")
+    return data

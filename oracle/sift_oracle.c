@@ -115,6 +115,50 @@ int64_t oracle_read_chunk(const uint8_t *in, size_t avail, uint8_t chunk_type[4]
     return (int64_t)(8 + (uint64_t)len + 4);
 }
 
+/* ---- document.rs:50-51: chunk types ------------------------------------ */
+static const uint8_t k_amrg[4] = {'A', 'M', 'R', 'G'};
+static const uint8_t k_send[4] = {'S', 'E', 'N', 'D'};
+
+/* ---- document.rs:53-60: write_document (payload = encode_document's bytes) */
+int64_t oracle_write_document(const uint8_t *payload, uint64_t len, uint8_t *out, size_t cap) {
+    int64_t n = oracle_write_header(out, cap);                       /* :54 */
+    if (n < 0) return n;
+    size_t pos = (size_t)n;
+    n = oracle_write_chunk(k_amrg, payload, len, out + pos, cap - pos); /* :55-56 */
+    if (n < 0) return n;
+    pos += (size_t)n;
+    n = oracle_write_chunk(k_send, NULL, 0, out + pos, cap - pos);   /* :57-58 */
+    if (n < 0) return n;
+    return (int64_t)(pos + (size_t)n);
+}
+
+/* ---- document.rs:62-77: read_document ---------------------------------- */
+int64_t oracle_read_document(const uint8_t *in, size_t avail, uint64_t *payload_off,
+                             uint32_t *payload_len, int *stage) {
+    uint8_t type[4];
+    uint64_t off = 0;
+    uint32_t len = 0;
+    *stage = 0;
+    int64_t n = oracle_read_header(in, avail);                       /* :63 */
+    if (n < 0) return n;
+    size_t pos = (size_t)n;
+    *stage = 1;
+    n = oracle_read_chunk(in + pos, avail - pos, type, &off, &len);  /* :64 */
+    if (n < 0) return n;
+    *stage = 2;
+    if (memcmp(type, k_amrg, 4) != 0) return -ORACLE_ERR_READ;       /* :65-67 */
+    *payload_off = pos + off;
+    *payload_len = len;
+    pos += (size_t)n;
+    *stage = 3;                                                      /* :69 decode_document is the caller's */
+    n = oracle_read_chunk(in + pos, avail - pos, type, &off, &len);  /* :71 */
+    if (n < 0) return n;
+    *stage = 4;
+    if (memcmp(type, k_send, 4) != 0) return -ORACLE_ERR_READ;       /* :72-74 */
+    *stage = 5;
+    return (int64_t)(pos + (size_t)n);
+}
+
 /* ---- bench helper ------------------------------------------------------ */
 uint32_t oracle_crc_repeat(const uint8_t *buf, size_t len, int passes) {
     uint32_t c = 0xffffffffu;

@@ -66,6 +66,18 @@ int64_t oracle_write_chunk(const uint8_t chunk_type[4], const uint8_t *data, uin
 int64_t oracle_read_chunk(const uint8_t *in, size_t avail, uint8_t chunk_type[4],
                           uint64_t *data_off, uint32_t *data_len);
 
+/* document.rs:50-60 -- write_document's framing around an opaque payload (the
+ * bytes encode_document returned): header, AMRG chunk, empty SEND chunk.
+ * Returns bytes written or -ORACLE_ERR_*. */
+int64_t oracle_write_document(const uint8_t *payload, uint64_t len, uint8_t *out, size_t cap);
+/* document.rs:62-77 -- read_document's framing: read_header, read_chunk +
+ * expect_type(AMRG), [decode_document: the caller's], read_chunk +
+ * expect_type(SEND).  Returns bytes consumed or -ORACLE_ERR_*; *stage says how
+ * far it got (0 header, 1 AMRG chunk, 2 AMRG type, 3 SEND chunk, 4 SEND type,
+ * 5 all good); payload offset / length are valid from stage 3 on. */
+int64_t oracle_read_document(const uint8_t *in, size_t avail, uint64_t *payload_off,
+                             uint32_t *payload_len, int *stage);
+
 /* Bounded timing helper for bench.py's cpu_baseline leg: runs
  * oracle_crc_compute over buf `passes` times, returns the final state. */
 uint32_t oracle_crc_repeat(const uint8_t *buf, size_t len, int passes);

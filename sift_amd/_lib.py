@@ -44,7 +44,7 @@ EXPORTS = (
     "sift_digest_new", "sift_digest_update", "sift_digest_update_device",
     "sift_digest_finalize", "sift_crc32_concat", "sift_chunk_crc_device", "sift_crc32_batch_device", "sift_read_chunks_device", "sift_read_documents_device", "sift_write_chunk_crcs_device",
     "sift_write_header", "sift_read_header", "sift_write_chunk", "sift_read_chunk",
-    "sift_expect_type",
+    "sift_expect_type", "sift_write_document", "sift_read_document",
 )
 
 
@@ -122,6 +122,10 @@ def _load() -> C.CDLL:
     L.sift_write_chunk.argtypes = [i32, C.c_char_p, vp, u64, vp, C.c_size_t]
     L.sift_read_chunk.restype = i64
     L.sift_read_chunk.argtypes = [i32, vp, C.c_size_t, vp, C.POINTER(u64), C.POINTER(u32)]
+    L.sift_write_document.restype = i64
+    L.sift_write_document.argtypes = [i32, vp, u64, vp, C.c_size_t]
+    L.sift_read_document.restype = i64
+    L.sift_read_document.argtypes = [i32, vp, C.c_size_t, C.POINTER(u64), C.POINTER(u32), C.POINTER(i32)]
     L.sift_expect_type.restype = i32
     L.sift_expect_type.argtypes = [C.c_char_p, C.c_char_p]
     return L

@@ -104,6 +104,36 @@ def read_chunk(reader, pos: int = 0, device: int | None = None):
     return Chunk(bytes(t), a[start:start + ln.value].tobytes()), pos + int(n)
 
 
+def write_document(payload, writer: bytearray, device: int | None = None) -> None:
+    """document.rs:53-60 with `payload` standing for encode_document's bytes:
+    header, AMRG chunk, empty SEND chunk."""
+    data = np.frombuffer(payload, dtype=np.uint8)
+    out = np.empty(data.size + _lib.HEADER_LEN + 24, dtype=np.uint8)
+    n = lib.sift_write_document(_dev(device), data.ctypes.data if data.size else None, data.size,
+                                out.ctypes.data, out.size)
+    if n < 0:
+        _raise(n)
+    writer += out[:n].tobytes()
+
+
+def read_document(reader, device: int | None = None, decode=None):
+    """document.rs:62-77.  Returns the AMRG payload (or decode(payload) if a decoder
+    is given; it runs where the reference runs decode_document, before the SEND
+    chunk's verdict is raised)."""
+    a = np.frombuffer(reader, dtype=np.uint8)
+    off, ln, stage = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    n = lib.sift_read_document(_dev(device), a.ctypes.data if a.size else None, a.size,
+                               C.byref(off), C.byref(ln), C.byref(stage))
+    payload = None
+    if stage.value >= 3:
+        payload = a[off.value:off.value + ln.value].tobytes()
+        if decode is not None:
+            payload = decode(payload)
+    if n < 0:
+        _raise(n)
+    return payload
+
+
 def _windows(base: torch.Tensor, offsets, avail):
     """Descriptor pointers for host sequences or int64 device tensors."""
     from .crc import _descriptors

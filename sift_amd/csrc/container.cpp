@@ -89,6 +89,52 @@ int64_t sift_read_chunk(int device, const uint8_t* in, size_t avail, uint8_t chu
     return int64_t(12 + uint64_t(len));
 }
 
+namespace {
+const uint8_t kAutomergeChunk[4] = {'A', 'M', 'R', 'G'};  // document.rs:50
+const uint8_t kEndChunk[4] = {'S', 'E', 'N', 'D'};        // document.rs:51
+}  // namespace
+
+int64_t sift_write_document(int device, const uint8_t* payload, uint64_t len, uint8_t* out, size_t cap) {
+    int64_t n = sift_write_header(out, cap);  // document.rs:54
+    if (n < 0) return n;
+    size_t pos = size_t(n);
+    n = sift_write_chunk(device, kAutomergeChunk, payload, len, out + pos, cap - pos);  // :55-56
+    if (n < 0) return n;
+    pos += size_t(n);
+    n = sift_write_chunk(device, kEndChunk, nullptr, 0, out + pos, cap - pos);  // :57-58
+    if (n < 0) return n;
+    return int64_t(pos + size_t(n));
+}
+
+int64_t sift_read_document(int device, const uint8_t* in, size_t avail, uint64_t* payload_off,
+                           uint32_t* payload_len, int* stage) {
+    if (!payload_off || !payload_len) return -SIFT_ERR_INVALID_ARG;
+    int dummy = 0;
+    int* st = stage ? stage : &dummy;
+    uint8_t type[4];
+    uint64_t off = 0;
+    uint32_t len = 0;
+    *st = SIFT_DOC_HEADER;
+    int64_t n = sift_read_header(in, avail);  // document.rs:63
+    if (n < 0) return n;
+    size_t pos = size_t(n);
+    *st = SIFT_DOC_AMRG_CHUNK;
+    n = sift_read_chunk(device, in + pos, avail - pos, type, &off, &len);  // :64
+    if (n < 0) return n;
+    *st = SIFT_DOC_AMRG_TYPE;
+    if (sift_expect_type(type, kAutomergeChunk) != SIFT_OK) return -SIFT_ERR_READ;  // :65-67
+    *payload_off = pos + off;
+    *payload_len = len;
+    pos += size_t(n);
+    *st = SIFT_DOC_SEND_CHUNK;  // :69, decode_document, is the caller's
+    n = sift_read_chunk(device, in + pos, avail - pos, type, &off, &len);  // :71
+    if (n < 0) return n;
+    *st = SIFT_DOC_SEND_TYPE;
+    if (sift_expect_type(type, kEndChunk) != SIFT_OK) return -SIFT_ERR_READ;  // :72-74
+    *st = SIFT_DOC_DONE;
+    return int64_t(pos + size_t(n));
+}
+
 int sift_expect_type(const uint8_t chunk_type[4], const uint8_t expected[4]) {
     return std::memcmp(chunk_type, expected, 4) == 0 ? SIFT_OK : SIFT_ERR_READ;  // :86-95
 }

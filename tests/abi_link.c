@@ -16,7 +16,7 @@ int main(void) {
         (void *)sift_digest_update_device, (void *)sift_digest_finalize, (void *)sift_crc32_concat,
         (void *)sift_chunk_crc_device, (void *)sift_crc32_batch_device, (void *)sift_read_chunks_device,
         (void *)sift_read_documents_device, (void *)sift_write_chunk_crcs_device, (void *)sift_write_header, (void *)sift_read_header,
-        (void *)sift_write_chunk, (void *)sift_read_chunk, (void *)sift_expect_type,
+        (void *)sift_write_chunk, (void *)sift_read_chunk, (void *)sift_expect_type, (void *)sift_write_document, (void *)sift_read_document,
     };
     unsigned char hdr[SIFT_HEADER_LEN];
     sift_digest d;

@@ -97,3 +97,68 @@ def test_chunk_crc_device_resident(gpu, oracle):
                                               torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert (int(out.item()) & 0xFFFFFFFF) == struct.unpack(">I", ser[-4:].tobytes())[0]
+
+
+def test_write_and_read_document_through_the_c_abi(gpu, oracle):
+    # document.rs:53-77: sift_write_document / sift_read_document against the oracle and the
+    # golden file, then the same nine mutations the many-files kernel is tested with
+    from oracle import py_oracle
+    from sift_amd import container
+    g = _golden()["document_framing"]
+    payload, want = bytes.fromhex(g["amrg_data"]), bytes.fromhex(g["file"])
+    out = bytearray()
+    container.write_document(payload, out)
+    assert bytes(out) == want == oracle.write_document(payload)
+    assert container.read_document(want) == payload
+    rng = np.random.default_rng(61)
+    kinds = {1: "Read", 3: "ReadInvalidChunkSize", 5: "ReadCrcMismatch"}
+    for n in (0, 1, 777, 100_000, (3 << 20) + 5):
+        payload = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        out = bytearray()
+        container.write_document(payload, out)
+        good = bytes(out)
+        assert good == oracle.write_document(payload)
+        for mutate in range(10):
+            f = bytearray(good)
+            if mutate == 1:
+                f[3] ^= 0x01
+            elif mutate == 2 and n:
+                f[17 + n // 2] ^= 0x80
+            elif mutate == 3:
+                f = bytearray(py_oracle.HEADER + oracle.write_chunk(b"SEND", payload) + oracle.write_chunk(b"SEND", b""))
+            elif mutate == 4:
+                f = bytearray(py_oracle.HEADER + oracle.write_chunk(b"AMRG", payload) + oracle.write_chunk(b"AMRG", b""))
+            elif mutate == 5:
+                f = f[:-2]
+            elif mutate == 6:
+                f[-1] ^= 0x04
+            elif mutate == 7:
+                f = f[:5]
+            elif mutate == 8:
+                f += b"trailing bytes are ignored by read_document"
+            elif mutate == 9:
+                f[9:13] = struct.pack(">I", (1 << 30) + 1)
+            status, stage, off, ln, used = oracle.read_document(bytes(f))
+            seen = []
+            if status == 0:
+                assert container.read_document(bytes(f), decode=lambda p: seen.append(p) or p) == payload
+                assert seen == [payload]
+            else:
+                with pytest.raises(container.Error) as e:
+                    container.read_document(bytes(f), decode=lambda p: seen.append(p) or p)
+                assert e.value.kind == kinds[status], (n, mutate)
+                # the decoder ran exactly when the reference would have reached decode_document
+                assert (len(seen) == 1) == (stage >= 3), (n, mutate, stage)
+    # the C entry point reports the same stage as the oracle
+    import ctypes as C
+    from sift_amd import _lib
+    bad = bytearray(want)
+    bad[-1] ^= 1
+    a = np.frombuffer(bytes(bad), dtype=np.uint8)
+    off, ln, stage = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    rc = _lib.lib.sift_read_document(0, a.ctypes.data, a.size, C.byref(off), C.byref(ln), C.byref(stage))
+    assert (-rc, stage.value, off.value, ln.value) == oracle.read_document(bytes(bad))[:4]
+    # output too small: Error::Write from whichever write runs out of room
+    small = np.empty(len(want) - 1, dtype=np.uint8)
+    p = np.frombuffer(bytes.fromhex(g["amrg_data"]), dtype=np.uint8)
+    assert _lib.lib.sift_write_document(0, p.ctypes.data, p.size, small.ctypes.data, small.size) == -_lib.ERR_WRITE

@@ -114,3 +114,35 @@ def test_container_errors(oracle):
             py_oracle.read_header(bytes(b))
     with pytest.raises(py_oracle.ContainerError):
         py_oracle.read_header(py_oracle.HEADER[:8])
+
+
+def test_document_framing_oracles_agree_with_golden(oracle):
+    # document.rs:53-77 with an opaque payload: C oracle == Python oracle == the fixture built
+    # independently with struct.pack + zlib (tests/golden/make_golden.py)
+    import json
+    import os
+    from oracle import py_oracle
+    with open(os.path.join(os.path.dirname(__file__), "golden", "container_cases.json")) as f:
+        g = json.load(f)["document_framing"]
+    payload, want = bytes.fromhex(g["amrg_data"]), bytes.fromhex(g["file"])
+    assert oracle.write_document(payload) == want == py_oracle.write_document(payload)
+    assert oracle.read_document(want) == (0, 5, 17, len(payload), len(want))
+    assert py_oracle.read_document(want) == payload
+    assert oracle.write_document(b"") == py_oracle.write_document(b"")
+    # the stage at which each damaged file stops, and with which error
+    cases = {
+        "magic": (bytes([want[0] ^ 1]) + want[1:], 1, 0),
+        "short header": (want[:5], 1, 0),
+        "payload bit": (want[:40] + bytes([want[40] ^ 8]) + want[41:], 5, 1),
+        "oversize": (want[:9] + b"\x40\x00\x00\x01" + want[13:], 3, 1),
+        "amrg type": (py_oracle.HEADER + py_oracle.write_chunk(b"AMRX", payload) + py_oracle.write_chunk(b"SEND", b""), 1, 2),
+        "send cut": (want[:-1], 1, 3),
+        "send crc": (want[:-1] + bytes([want[-1] ^ 1]), 5, 3),
+        "send type": (py_oracle.HEADER + py_oracle.write_chunk(b"AMRG", payload) + py_oracle.write_chunk(b"AMRG", b""), 1, 4),
+    }
+    for name, (f_, status, stage) in cases.items():
+        got = oracle.read_document(f_)
+        assert got[:2] == (status, stage), (name, got)
+        with pytest.raises(py_oracle.ContainerError) as e:
+            py_oracle.read_document(f_)
+        assert {"Read": 1, "ReadInvalidChunkSize": 3, "ReadCrcMismatch": 5}[e.value.kind] == status, name

@@ -105,3 +105,21 @@ def test_stitch_many_ranges_single_process(oracle):
     for r, (a, b) in enumerate(zip(cuts, cuts[1:])):
         pairs.append((oracle.compute(0xFFFFFFFF if r == 0 else 0, full[a:b]), b - a))
     assert sharded.stitch(pairs) == oracle.compute(0xFFFFFFFF, full)
+
+
+def test_bench_dry_collective_two_ranks():
+    # bench.py's own N > 1 exchange, launched the way the driver launches the bench
+    # (torch.distributed.run, 2 ranks), on CPU tensors over gloo: everything of the
+    # multi-GPU bench leg except the backend string and the kernel.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+         os.path.join(root, "bench.py"), "--dry-collective"],
+        capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines and json.loads(lines[-1]) == {"dry_collective": "ok", "world": 2, "steps": 3}
