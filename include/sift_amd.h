@@ -98,6 +98,10 @@ enum {
     SIFT_TUNE_BATCH_WAVE_MAX = 3,/* bytes of CRC span one wave keeps before the item is cut;
                                     0 (default) = 256 KiB for n >= 4096 items, else 32 KiB */
     SIFT_TUNE_BATCH_PIECE_LOG2 = 4, /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
+    SIFT_TUNE_HOST_COPY_THREADS = 6, /* host threads (incl. the caller's) that fill the pinned bounce
+                                    ring for pageable input of 4 MiB and more, 1..16 (default 4);
+                                    0: always the staged hipMemcpyAsync path.  Set before the first
+                                    host-input call on a device. */
     SIFT_TUNE_BATCH_PLAN = 5     /* 1 (default): up to 64 items (not whole documents) go straight to the
                                     piece kernel, which plans them itself; 0: always two launches */
 };
@@ -153,9 +157,11 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf
 
 /* Host-resident input, reduced on the GPU; returns the new state through
  * `*out`.  Pinned memory (hipHostMalloc / hipHostRegister) is read by the
- * kernel in place over PCIe; pageable memory is staged in pipelined pieces
- * (copy of piece i+1 overlaps the kernel of piece i).  This is the signature
- * the reference's compute(crc, buf) maps to one-to-one. */
+ * kernel in place over PCIe.  Pageable memory of 4 MiB and more is copied by a
+ * few host threads into a ring of pinned 8 MiB slots which the kernel reads in
+ * place, slot k+1 being filled while slot k is read; smaller pageable inputs
+ * are staged with hipMemcpyAsync.  This is the signature the reference's
+ * compute(crc, buf) maps to one-to-one. */
 int sift_crc32_compute_host(int device, uint32_t state, const void *buf, uint64_t len,
                             uint32_t *out);
 

@@ -29,6 +29,7 @@ TUNE_BATCH_CUT = 2
 TUNE_BATCH_WAVE_MAX = 3
 TUNE_BATCH_PIECE_LOG2 = 4
 TUNE_BATCH_PLAN = 5
+TUNE_HOST_COPY_THREADS = 6
 
 HEADER_LEN = 9
 CHUNK_SIZE_LIMIT = 1024 * 1024 * 1024

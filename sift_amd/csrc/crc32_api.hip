@@ -9,6 +9,8 @@
 #include <cstring>
 #include <mutex>
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -32,7 +34,8 @@ std::atomic<bool> g_single_launch{true};
 std::atomic<int> g_batch_cut{1};          // 0: every item stays on one wave (round-1 behaviour, A/B only)
 std::atomic<int> g_batch_wave_max{0};     // bytes a single wave keeps; 0 = chosen from n (run_batch)
 std::atomic<int> g_batch_piece_log2{kPieceMinLog2};
-std::atomic<int> g_batch_plan{1};         // 0: always file through the wave kernel, even for few items
+std::atomic<int> g_batch_plan{1};
+std::atomic<int> g_host_copy_threads{4};  // threads that fill the pinned bounce ring (pageable host input)         // 0: always file through the wave kernel, even for few items
 
 int fail_hip(hipError_t e, const char* what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -69,6 +72,83 @@ const X2nTable& x2n() {
     return t;
 }
 
+// Pageable host input (sift_crc32_compute_host): a few host threads copy the
+// caller's bytes into a ring of pinned slots while the tile kernel reads the
+// slots filled before IN PLACE over PCIe (pinned memory is device-addressable),
+// the running state chained on the device.  Each byte crosses PCIe once, and no
+// staging copy runs on the GPU; several memcpy threads are needed because one
+// core copies slower than the link carries.
+constexpr int kBounceSlots = 4;
+constexpr size_t kBounceSlotBytes = 8ull << 20;
+constexpr uint64_t kBounceMin = 4ull << 20;  // below this the plain staged copy is as fast and simpler
+
+class CopyCrew {
+   public:
+    explicit CopyCrew(int helpers) {
+        for (int i = 0; i < helpers; ++i) threads_.emplace_back([this, i] { work(i + 1); });
+    }
+    ~CopyCrew() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    // memcpy(dst, src, n) split over the helper threads; returns at once, wait()
+    // returns when the copy is complete.  The caller is free in between (it
+    // launches the kernel over the slot filled before).
+    void begin(uint8_t* dst, const uint8_t* src, size_t n) {
+        if (threads_.empty()) {
+            std::memcpy(dst, src, n);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            dst_ = dst;
+            src_ = src;
+            n_ = n;
+            pending_ = (int)threads_.size();
+            ++generation_;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+    }
+
+   private:
+    void share(int part, int parts) {  // part 1..parts
+        --part;
+        const size_t chunk = ((n_ + parts - 1) / parts + 4095) & ~size_t(4095);  // whole pages, never 0
+        const size_t lo = std::min(n_, chunk * part), hi = std::min(n_, lo + chunk);
+        if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void work(int part) {
+        unsigned seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lock(m_);
+            cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            lock.unlock();
+            share(part, (int)threads_.size());
+            lock.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    uint8_t* dst_ = nullptr;
+    const uint8_t* src_ = nullptr;
+    size_t n_ = 0;
+    int pending_ = 0;
+    unsigned generation_ = 0;
+    bool stop_ = false;
+};
+
 // Device scratch of the calls issued on one stream.  Calls on one stream run in
 // order on the device, so they can share a block; calls on different streams
 // may overlap, so every stream gets blocks of its own (allocated on its first
@@ -97,6 +177,11 @@ struct DeviceCtx {
     std::atomic<unsigned> h_next{0};
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    // pinned bounce ring for pageable input
+    uint8_t* h_bounce = nullptr;  // kBounceSlots * kBounceSlotBytes, pinned
+    uint8_t* d_bounce = nullptr;  // the same memory as the device addresses it
+    hipEvent_t bounce_read[kBounceSlots] = {};
+    CopyCrew* crew = nullptr;
     std::mutex host_path_mutex;
     struct MatsEntry {
         int64_t tpg = -1;
@@ -120,6 +205,10 @@ void destroy_ctx(DeviceCtx* c) {  // the device is current
     (void)hipFree(c->d_tabs);
     (void)hipFree(c->d_state);
     if (c->h_results) (void)hipHostFree(c->h_results);
+    delete c->crew;
+    if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+    for (hipEvent_t e : c->bounce_read)
+        if (e) (void)hipEventDestroy(e);
     for (auto& kv : c->per_stream) {
         (void)hipFree(kv.second.compute_ws);
         (void)hipFree(kv.second.batch);
@@ -427,6 +516,14 @@ int ensure_staging(DeviceCtx* c) {  // under host_path_mutex
     }
     if (!c->copy_stream) SIFT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->work_stream) SIFT_HIP(hipStreamCreateWithFlags(&c->work_stream, hipStreamNonBlocking));
+    if (!c->h_bounce) {
+        SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bounce), kBounceSlots * kBounceSlotBytes,
+                               hipHostMallocDefault));
+        SIFT_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_bounce), c->h_bounce, 0));
+    }
+    for (int i = 0; i < kBounceSlots; ++i)
+        if (!c->bounce_read[i]) SIFT_HIP(hipEventCreateWithFlags(&c->bounce_read[i], hipEventDisableTiming));
+    if (!c->crew) c->crew = new CopyCrew(std::max(0, g_host_copy_threads.load()));
     c->staging_ready = true;  // set last: a partial failure above is retried, not skipped
     return SIFT_OK;
 }
@@ -542,6 +639,10 @@ int sift_tune(int key, int value) {
             return SIFT_OK;
         case SIFT_TUNE_BATCH_CUT:
             g_batch_cut = value != 0;
+            return SIFT_OK;
+        case SIFT_TUNE_HOST_COPY_THREADS:
+            if (value < 0 || value > 16) break;
+            g_host_copy_threads = value;  // takes effect for devices not yet used for host input
             return SIFT_OK;
         case SIFT_TUNE_BATCH_PLAN:
             g_batch_plan = value != 0;
@@ -687,6 +788,53 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     // result provably comes from the device path.
     uint64_t off = 0;
     int piece = 0;
+    if (len >= kBounceMin && g_host_copy_threads.load() > 0) {
+        // Pageable input, large: host threads fill pinned slots, the kernel reads
+        // each slot in place; slot k % kBounceSlots is refilled once the kernel
+        // that read it has finished.
+        // Piece k's copy runs on the helper threads while this thread launches the
+        // kernel over piece k-1.
+        // Piece sizes ramp up 1, 2, 4, 8 MiB and taper down again towards the end: the
+        // first copy and the last kernel are the two steps nothing overlaps.
+        auto piece_bytes = [&](int k, uint64_t at) -> uint64_t {
+            const uint64_t left = len - at, mib = 1ull << 20;
+            if (left <= mib) return left;
+            const uint64_t grow = mib << std::min(k, 3);
+            const uint64_t half = std::max<uint64_t>(mib, (left / 2 + mib - 1) / mib * mib);
+            return std::min<uint64_t>(std::min<uint64_t>(kBounceSlotBytes, grow), half);
+        };
+        auto slot_of = [&](int k) { return (size_t)(k % kBounceSlots) * kBounceSlotBytes; };
+        auto start_copy = [&](int k, uint64_t at) -> hipError_t {
+            if (k >= kBounceSlots) {  // the kernel that read this slot last must be done
+                hipError_t e = hipEventSynchronize(c->bounce_read[k % kBounceSlots]);
+                if (e != hipSuccess) return e;
+            }
+            c->crew->begin(c->h_bounce + slot_of(k), src + at, piece_bytes(k, at));
+            return hipSuccess;
+        };
+        hipError_t e = start_copy(0, 0);
+        while (e == hipSuccess) {
+            const uint64_t n = piece_bytes(piece, off);
+            const bool last = off + n >= len;
+            c->crew->wait();  // piece `piece` is in its slot
+            if (!last && (e = start_copy(piece + 1, off + n)) != hipSuccess) break;
+            rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_bounce + slot_of(piece), n, 0u,
+                                last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream);
+            if (rc != SIFT_OK) break;
+            if ((e = hipEventRecord(c->bounce_read[piece % kBounceSlots], c->work_stream)) != hipSuccess) break;
+            off += n;
+            ++piece;
+            if (last) break;
+        }
+        if (rc != SIFT_OK || e != hipSuccess) {
+            c->crew->wait();
+            (void)hipStreamSynchronize(c->work_stream);
+            return rc != SIFT_OK ? rc : fail_hip(e, "pinned bounce ring");
+        }
+        SIFT_HIP(hipStreamSynchronize(c->work_stream));
+        *out = *res;
+        return SIFT_OK;
+    }
     // An error in the middle leaves copies from the caller's buffer in flight:
     // drain both streams before handing the buffer back.
     auto bail = [&](int code) {

@@ -81,7 +81,9 @@ def test_alignments_vs_oracle(gpu, oracle):
 
 
 def test_host_buffer_path(gpu, oracle):
-    for n in (0, 1, 9, 4096, 100000, (32 << 20) - 1, (32 << 20), (32 << 20) + 1, (70 << 20) + 13):
+    # pageable input: staged copy below 4 MiB, pinned bounce ring of 8 MiB slots from there on
+    for n in (0, 1, 9, 4096, 100000, (4 << 20) - 1, 4 << 20, (8 << 20) - 1, 8 << 20, (8 << 20) + 1, (16 << 20) + 5,
+              (32 << 20) - 1, (32 << 20), (32 << 20) + 1, (70 << 20) + 13):
         buf = _rand(n, seed=n + 1)
         assert gpu.compute(0xFFFFFFFF, buf) == oracle.compute(0xFFFFFFFF, buf), n
         assert gpu.compute(0xFFFFFFFF, buf.tobytes()) == zlib.crc32(buf.tobytes()) ^ 0xFFFFFFFF
