@@ -158,7 +158,17 @@ struct StreamScratch {
     uint32_t* compute_ws = nullptr;  // kSlotWords, zero between calls (sift_crc32_compute_* with workspace NULL)
     uint8_t* batch = nullptr;        // batch entry points: counters | records | piece list; counters zero between calls
     size_t batch_bytes = 0;
+    // Pageable host descriptors of up to kDescStageBytes per call are copied by the
+    // CPU into one of two pinned buffers which the kernels read in place (no copy
+    // command: hipMemcpyAsync from pageable memory costs 100-300 us of fixed time
+    // at these sizes).  A buffer is reused once the call that read it has finished.
+    uint8_t* h_desc = nullptr;       // 2 * kDescStageBytes, pinned
+    uint8_t* d_desc = nullptr;       // the same memory as the device addresses it
+    hipEvent_t desc_read[2] = {nullptr, nullptr};
+    bool desc_used[2] = {false, false};
+    unsigned desc_next = 0;
 };
+constexpr size_t kDescStageBytes = 1u << 20;
 
 struct DeviceCtx {
     int device = -1;
@@ -212,6 +222,9 @@ void destroy_ctx(DeviceCtx* c) {  // the device is current
     for (auto& kv : c->per_stream) {
         (void)hipFree(kv.second.compute_ws);
         (void)hipFree(kv.second.batch);
+        if (kv.second.h_desc) (void)hipHostFree(kv.second.h_desc);
+        for (hipEvent_t e : kv.second.desc_read)
+            if (e) (void)hipEventDestroy(e);
     }
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
@@ -1031,18 +1044,45 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     }
     const size_t copy_bytes = (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
-    uint8_t* d_desc = nullptr;
-    if (copy_bytes) SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), copy_bytes, st));
-    uint8_t* d_next = d_desc;
-    if (w_off == Where::Host) {
-        // pageable source: the runtime has consumed it when the call returns
-        SIFT_HIP(hipMemcpyAsync(d_next, offsets, 8ull * n, hipMemcpyHostToDevice, st));
-        dv_off = d_next;
-        d_next += 8ull * n;
-    }
-    if (w_len == Where::Host) {
-        SIFT_HIP(hipMemcpyAsync(d_next, lens, 8ull * n, hipMemcpyHostToDevice, st));
-        dv_len = d_next;
+    uint8_t* d_desc = nullptr;   // stream-ordered allocation (large descriptor arrays)
+    int stage_buf = -1;          // or one of the stream's two pinned buffers (small ones)
+    if (copy_bytes && copy_bytes <= kDescStageBytes) {
+        StreamScratch& ss = c->per_stream[st];
+        if (!ss.h_desc) {
+            uint8_t* h = nullptr;
+            SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 2 * kDescStageBytes, hipHostMallocDefault));
+            ss.h_desc = h;
+            SIFT_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ss.d_desc), h, 0));
+            for (int i = 0; i < 2; ++i)
+                SIFT_HIP(hipEventCreateWithFlags(&ss.desc_read[i], hipEventDisableTiming));
+        }
+        stage_buf = (int)(ss.desc_next++ & 1u);
+        if (ss.desc_used[stage_buf]) SIFT_HIP(hipEventSynchronize(ss.desc_read[stage_buf]));
+        uint8_t* hp = ss.h_desc + (size_t)stage_buf * kDescStageBytes;
+        const uint8_t* dp = ss.d_desc + (size_t)stage_buf * kDescStageBytes;
+        if (w_off == Where::Host) {
+            std::memcpy(hp, offsets, 8ull * n);
+            dv_off = dp;
+            hp += 8ull * n;
+            dp += 8ull * n;
+        }
+        if (w_len == Where::Host) {
+            std::memcpy(hp, lens, 8ull * n);
+            dv_len = dp;
+        }
+    } else if (copy_bytes) {
+        SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), copy_bytes, st));
+        uint8_t* d_next = d_desc;
+        if (w_off == Where::Host) {
+            // pageable source: the runtime has consumed it when the call returns
+            SIFT_HIP(hipMemcpyAsync(d_next, offsets, 8ull * n, hipMemcpyHostToDevice, st));
+            dv_off = d_next;
+            d_next += 8ull * n;
+        }
+        if (w_len == Where::Host) {
+            SIFT_HIP(hipMemcpyAsync(d_next, lens, 8ull * n, hipMemcpyHostToDevice, st));
+            dv_len = d_next;
+        }
     }
     b.offsets = static_cast<const uint64_t*>(dv_off);
     b.lens = static_cast<const uint64_t*>(dv_len);
@@ -1061,6 +1101,11 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         }
     }
     if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, st));
+    if (stage_buf >= 0) {
+        StreamScratch& ss = c->per_stream[st];
+        SIFT_HIP(hipEventRecord(ss.desc_read[stage_buf], st));
+        ss.desc_used[stage_buf] = true;
+    }
     return SIFT_OK;
 }
 

@@ -239,3 +239,50 @@ def test_batch_whole_chip_buffers_keep_their_slots(gpu):
             for i, (o, n) in enumerate(zip(offs, lens)):
                 want = (zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo
                 assert int(got[i]) == want, (lens, i, hex(int(got[i])), hex(want))
+
+
+def test_batch_argument_errors_and_edges(gpu, oracle):
+    import ctypes as C
+    from sift_amd import _lib, container
+    d = torch.arange(0, 256, dtype=torch.uint8, device="cuda").repeat(64)
+    out = torch.zeros(8, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    host = np.array([0, 8], dtype=np.uint64)
+    dev = torch.tensor([0, 8], dtype=torch.int64, device="cuda")
+    # one array on the host, the other on the device: refused, not dereferenced
+    rc = _lib.lib.sift_crc32_batch_device(0, 0, 0, d.data_ptr(), host.ctypes.data, dev.data_ptr(), 2, out.data_ptr(), s)
+    assert rc == _lib.ERR_INVALID_ARG and b"both" in _lib.lib.sift_last_error()
+    rc = _lib.lib.sift_crc32_batch_device(0, 0, 0, d.data_ptr(), dev.data_ptr(), host.ctypes.data, 2, out.data_ptr(), s)
+    assert rc == _lib.ERR_INVALID_ARG
+    rc = _lib.lib.sift_crc32_batch_device(0, 0, 0, d.data_ptr(), None, host.ctypes.data, 2, out.data_ptr(), s)
+    assert rc == _lib.ERR_INVALID_ARG
+    # n = 0 does nothing and succeeds
+    assert _lib.lib.sift_crc32_batch_device(0, 0, 0, d.data_ptr(), None, None, 0, out.data_ptr(), s) == _lib.OK
+    # pinned host descriptors are read in place
+    po = torch.tensor([3, 100, 0], dtype=torch.int64).pin_memory()
+    pl = torch.tensor([50, 5000, 16384], dtype=torch.int64).pin_memory()
+    rc = _lib.lib.sift_crc32_batch_device(0, 0xFFFFFFFF, 0xFFFFFFFF, d.data_ptr(), po.data_ptr(), pl.data_ptr(), 3,
+                                          out.data_ptr(), s)
+    assert rc == _lib.OK
+    torch.cuda.synchronize()
+    h = d.cpu().numpy()
+    assert [int(v) & 0xFFFFFFFF for v in out[:3].cpu().tolist()] == \
+        [oracle.crc32(h[3:53]), oracle.crc32(h[100:5100]), oracle.crc32(h[:16384])]
+    # the Python mirror refuses a window that reaches past `base` (no u64 wrap-around)
+    with pytest.raises(ValueError):
+        gpu.compute_batch(0, d, [d.numel() - 4], [5])
+    with pytest.raises(ValueError):
+        gpu.compute_batch(0, d, [(1 << 64) - 2], [3])
+    # exactly 64 and 65 items: the self-planned form and the filed form meet here
+    rng = np.random.default_rng(71)
+    for n in (64, 65):
+        lens = [int(x) for x in rng.integers(0, 200, size=n)]
+        offs = [int(x) for x in rng.integers(0, d.numel() - 200, size=n)]
+        got = gpu.compute_batch(0xFFFFFFFF, d, offs, lens, xor_out=0xFFFFFFFF).cpu().numpy().view(np.uint32)
+        assert [int(g) for g in got] == [oracle.crc32(h[o:o + m]) for o, m in zip(offs, lens)]
+    # back-to-back calls with host descriptors reuse the two pinned staging buffers
+    outs = [gpu.compute_batch(0xFFFFFFFF, d, [k, k + 1], [1000 + k, 7 * k], xor_out=0) for k in range(12)]
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert [int(v) & 0xFFFFFFFF for v in o.cpu().tolist()] == \
+            [oracle.compute(0xFFFFFFFF, h[k:k + 1000 + k]), oracle.compute(0xFFFFFFFF, h[k + 1:k + 1 + 7 * k])]
