@@ -48,10 +48,12 @@ int fail_hip(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return fail_hip(e__, #call); \
     } while (0)
 
-// Workspace slot, in u32 words: residues (two-launch form) | pad |
-// u64 XOR accumulator (own 128-B line) | u64 arrival counter (own line).
-constexpr size_t kExchangeWord = kMaxGroups + 32;  // accumulator; counter is 32 words on
-constexpr size_t kSlotWords = kMaxGroups + 96;
+// Workspace slot, in u32 words: residues (two-launch form) | pad | exchange
+// words of the single-launch form: a top word and one word per shard of 32
+// groups, each u64 on its own 128-B line.
+constexpr size_t kExchangeWord = kMaxGroups + 32;
+constexpr size_t kExchangeWords = 32 * (1 + kMaxGroups / 32);
+constexpr size_t kSlotWords = kExchangeWord + kExchangeWords;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
 // A stream's small scratch block: compute workspace | accumulators of the piece
 // kernel's self-planned form (kPlanMax records), all zero between calls.
@@ -723,11 +725,11 @@ int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t*
     uint32_t* ws = c->static_scratch;
     // The array keeps whatever the last call on this GPU left.  The kernels leave
     // the accumulator and the arrival counter at zero when they finish, but a call
-    // that was aborted does not: clear both (two 128-B lines) on the stream first.
+    // that was aborted does not: clear the exchange words on the stream first.
     // By a kernel, not hipMemsetAsync: captured into a HIP graph, the memset node gave
     // wrong results from the second replay on (ROCm 7.2, gfx950; the kernel form and
     // the eager memset are both fine).
-    launch_clear(ws + kExchangeWord, s);
+    launch_clear(ws + kExchangeWord, (int)kExchangeWords, s);
     SIFT_HIP(hipGetLastError());
     return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws, s);
 }
@@ -1026,7 +1028,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
             const size_t want = std::max<size_t>(need + need / 2, 512u << 10);
             uint8_t* fresh = nullptr;
             SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&fresh), want, st));
-            launch_clear(reinterpret_cast<uint32_t*>(fresh), st);  // the three counters
+            launch_clear(reinterpret_cast<uint32_t*>(fresh), 64, st);  // the three counters
             SIFT_HIP(hipGetLastError());
             if (ss.batch) SIFT_HIP(hipFreeAsync(ss.batch, st));
             ss.batch = fresh;

@@ -68,8 +68,8 @@ struct TileArgs {
     int64_t pad_tiles;         // all-zero virtual tiles in front of the first real one
     const DeviceTables* tabs;
     uint32_t* partial;         // [groups] residues, one per workgroup
-    uint32_t* exchange;        // single-launch finish: u64 XOR accumulator, and 128 B on a u64
-                               // arrival counter; both zero between calls
+    uint32_t* exchange;        // single-launch finish: 1 + kMaxGroups/32 u64 words, each on its own 128-B
+                               // line (top word, then one per shard of 32 groups); all zero between calls
     // Starting register, folded into the message: with h = head_skip leading
     // zero bytes the padded message is n + h bytes long and
     //   state * x^(8n) = (state * x^(-8h)) * x^(8(n+h)),
@@ -172,7 +172,7 @@ struct BatchArgs {
 
 void launch_batch(const BatchArgs& b, int groups, void* stream);
 void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream);
-void launch_clear(uint32_t* words, void* stream);
+void launch_clear(uint32_t* words, int n, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);
 void launch_combine(const uint32_t* partial, const FinalArgs& f, const CombineMats& m,

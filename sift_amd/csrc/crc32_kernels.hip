@@ -308,31 +308,44 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     if (tid == 0) a.partial[g] = x;
     return;
 #endif
-    // Exchange through two 8-byte agent-scope read-modify-write atomics, both
-    // sides (guide: Guideline 16 / microarch "Valid forms": atomics execute at
-    // the memory side, so neither L1 nor a per-XCD L2 can serve a stale copy
-    // and no cache write-back or invalidate is needed).  One lane XORs the
-    // weighted residue into the accumulator, WAITS for that atomic to return,
-    // and only then adds to the arrival counter.  The group whose add returns
-    // G-1 knows every other group's XOR has been performed; it swaps the
-    // accumulator out (leaving zero for the next call), zeroes the counter
-    // and finishes.
+    // Exchange: ONE returning 8-byte agent-scope atomic per level.  Groups meet in
+    // shards of 32 (g >> 5); a shard's word holds the XOR of the residues that
+    // have arrived in its low half and one arrival bit per member in its high
+    // half, and a group XORs in (its bit | its residue).  Read-modify-write atomics
+    // on one word are serialised at the memory side (microarch guide, "Valid
+    // forms": atomics both sides; neither L1 nor a per-XCD L2 holds a copy), so the
+    // OLD value a group gets back tells it exactly which members came before it
+    // and the XOR of their residues: the group that sees every other bit set is
+    // the shard's last and already holds the shard's total (old ^ own) -- no
+    // second atomic to count arrivals, no third to fetch the sum.  The shards'
+    // last groups meet the same way on the top word (one bit per shard), and the
+    // last of those finishes.  Each last arriver XORs the word's final value in
+    // again, which puts it back to zero for the next call (not waited for: the
+    // kernel's end orders it before the next launch).
     if (tid == 0) {
-        unsigned long long* accp = reinterpret_cast<unsigned long long*>(a.exchange);
-        unsigned long long* cntp = accp + 16;  // its own 128-byte line
-        // Returning form + explicit wait: the XOR has been performed at the
-        // memory side before the add can issue.
-        unsigned long long old =
-            __hip_atomic_fetch_xor(accp, (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
-        unsigned long long ticket =
-            __hip_atomic_fetch_add(cntp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == (unsigned long long)(G - 1u)) {
-            unsigned long long v =
-                __hip_atomic_exchange(accp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_exchange(cntp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            finish((uint32_t)v, f);
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(a.exchange);  // 128-B lines
+        const uint32_t nshards = (G + 31u) >> 5;
+        const uint32_t shard = (uint32_t)g >> 5, bit = (uint32_t)g & 31u;
+        const uint32_t members = G - (shard << 5) < 32u ? G - (shard << 5) : 32u;
+        const uint32_t full1 = members == 32u ? 0xFFFFFFFFu : (1u << members) - 1u;
+        unsigned long long* w1 = words + 16u * (1u + shard);
+        unsigned long long old = __hip_atomic_fetch_xor(w1, ((unsigned long long)(1u << bit) << 32) | x,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((uint32_t)(old >> 32) | (1u << bit)) != full1) return;
+        const uint32_t xs = (uint32_t)old ^ x;  // the shard's total
+        __hip_atomic_fetch_xor(w1, ((unsigned long long)full1 << 32) | xs, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t total = xs;
+        if (nshards > 1u) {
+            const uint32_t full2 = nshards == 32u ? 0xFFFFFFFFu : (1u << nshards) - 1u;
+            old = __hip_atomic_fetch_xor(words, ((unsigned long long)(1u << shard) << 32) | xs,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((uint32_t)(old >> 32) | (1u << shard)) != full2) return;
+            total = (uint32_t)old ^ xs;
+            __hip_atomic_fetch_xor(words, ((unsigned long long)full2 << 32) | total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
+        finish(total, f);
     }
 }
 
@@ -1084,11 +1097,13 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     if (!PLAN && tid == 0) leave_pieces(c, gridDim.x);
 }
 
-// Zeroes 64 words (two 128-B lines) of a workspace.
-__global__ __launch_bounds__(64) void crc32_clear_kernel(uint32_t* words) { words[threadIdx.x] = 0u; }
+// Zeroes `n` words of a workspace.
+__global__ __launch_bounds__(256) void crc32_clear_kernel(uint32_t* words, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) words[i] = 0u;
+}
 
-void launch_clear(uint32_t* words, void* stream) {
-    hipLaunchKernelGGL(crc32_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), words);
+void launch_clear(uint32_t* words, int n, void* stream) {
+    hipLaunchKernelGGL(crc32_clear_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), words, n);
 }
 
 void launch_batch(const BatchArgs& b, int groups, void* stream) {
