@@ -132,7 +132,7 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_stat
 /* The same computation for callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART
  * IN THE REFERENCE (it never leaves the CPU).  Like sift_crc32_compute_device with
- * workspace = NULL, except that the workspace is a 4.5 KiB array in the
+ * workspace = NULL, except that the workspace is an 8.3 KiB array in the
  * library's own static device memory (one copy per GPU, held until the process
  * ends) instead of a slot of the allocated ring, and that the call itself makes
  * no hipMalloc / hipFree or any other allocating call.  Requirements:
