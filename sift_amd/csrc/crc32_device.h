@@ -164,6 +164,7 @@ struct BatchArgs {
                           // 2: out[i] = status of read_document's framing on file i
                           // 3: store the CRC field of serialized chunk i (Chunk::write), out[i] = status
     uint32_t chunk_limit; // verify: container.rs:49 size cap
+    uint32_t items_per_wave;  // batch kernel: consecutive items a wave takes at a time, one per lane (1..64)
     uint32_t* out;
     uint32_t* data_len;   // verify, optional: data length of each chunk that parsed
     const DeviceTables* tabs;

@@ -447,8 +447,13 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // state bytes land in vectors 0 and 1, which are in tile 0 or, when tile 0
     // holds vector 0 alone, in tiles 0 and 1: both are peeled.
     u32x4 acc = {0u, 0u, 0u, 0u};
+    if (vi >= 0) acc = vbase[vi];
+    // the < 16 bytes behind the last whole vector: lane k fetches byte k now, beside
+    // the data, instead of one lane fetching them after everything else
+    const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
+    uint32_t tb = 0;
+    if (lane < tail_len) tb = reinterpret_cast<const uint8_t*>(v1 << 4)[lane];
     if (vi >= 0) {
-        acc = vbase[vi];
         if (vi == 0 && h) acc = mask_head(acc, h);
         acc = fold_state(acc, vi, h, state);
     }
@@ -477,13 +482,70 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
     r = gf2_mulmod(r, aw);
     r = wave_xor(r);
-    // trailing bytes after the last whole vector
-    const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
-    if (tail_len) {
-        const uint8_t* tail = reinterpret_cast<const uint8_t*>(v1 << 4);
-        if (lane == 0)
-            for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, tail[i]);
-        r = __shfl(r, 0, 64);
+    // trailing bytes: every lane walks them alike (no divergence, no broadcast)
+    for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, __shfl(tb, (int)i, 64));
+    return r;
+}
+
+// CRC of a span of 32..240 bytes by ONE 16-LANE GROUP: a 16-byte vector per lane,
+// so the span's body (at most 16 vectors) is a single tile and there is no Horner
+// step: fold the four words, weight by the lane's place, XOR over the group.
+// Four spans per wave at a time.  Every lane of the wave calls this; `on` says
+// whether the lane's group has a span.  The register over the whole span comes
+// back in every lane of the group.
+__device__ __forceinline__ uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+                                              const uint32_t* ldsX, uint32_t lane, uint32_t aw16) {
+    const uint32_t l16 = lane & 15u, gbase = lane & 48u;
+    const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
+    const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
+    const int32_t nvec = (int32_t)(v1 - v0);  // 2..16 for 32 <= len <= 240
+    const uint32_t h = (uint32_t)(addr & 15u);
+    const int32_t vi = nvec - 16 + (int32_t)l16;  // the tile is aligned to the end of the body
+    const uint32_t tail_len = on ? (uint32_t)((addr + len) & 15u) : 0u;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    uint32_t tb = 0;
+    if (on) {
+        if (vi >= 0) acc = reinterpret_cast<const u32x4*>(v0 << 4)[vi];
+        if (l16 < tail_len) tb = reinterpret_cast<const uint8_t*>(v1 << 4)[l16];
+        if (vi >= 0) {
+            if (vi == 0 && h) acc = mask_head(acc, h);
+            acc = fold_state(acc, vi, h, state);
+        }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+    r = gf2_mulmod(r, aw16);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) r ^= __shfl_xor(r, off, 64);
+    for (uint32_t i = 0; __any(i < tail_len); ++i) {
+        const uint32_t byte = __shfl(tb, (int)(gbase + i), 64);
+        if (i < tail_len) r = crc_step_byte(r, byte);
+    }
+    return r;
+}
+
+// CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
+// bytes are fetched first, all at once, then walked with the bitwise recurrence.
+__device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on) {
+    uint32_t r = state;
+    on = on && len != 0u;
+    uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (on) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) w[k >> 2] |= (uint32_t)ptr[k < len ? k : len - 1u] << (8u * (k & 3u));
+    }
+    if (__any(on && len > 8u)) {  // most such spans are a bare chunk type (4 bytes)
+        if (on) {
+#pragma unroll
+            for (uint32_t k = 8; k < 31u; ++k)
+                w[k >> 2] |= (uint32_t)ptr[k < len ? k : len - 1u] << (8u * (k & 3u));
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (uint32_t k = 0; k < 31u; ++k)
+            if (k < len) r = crc_step_byte(r, (w[k >> 2] >> (8u * (k & 3u))) & 0xffu);
     }
     return r;
 }
@@ -570,7 +632,7 @@ __device__ __forceinline__ bool file_span(const BatchArgs& b, uint32_t item, con
 // ReadInvalidChunkSize (3) or ReadCrcMismatch (5), raised in the reference's
 // order; *dlen is the chunk's data length once the length field has been read.
 // The checks that come before the CRC (:48-60) are split off so that the caller
-// can file a long chunk for the piece kernel between the two.
+// lane that parses a chunk can hand its span on (wave, group, lane, or the piece kernel).
 __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t avail,
                                                     uint32_t limit, uint32_t* dlen) {
     *dlen = 0;
@@ -582,21 +644,88 @@ __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t
     return 0;
 }
 
-__device__ __forceinline__ uint32_t read_chunk_wave(const uint8_t* ptr, uint64_t avail,
-                                                    uint32_t limit, uint32_t* dlen,
-                                                    const uint32_t* ldsY, const uint32_t* ldsX,
-                                                    uint32_t lane, uint32_t lane32, uint32_t aw) {
-    const uint32_t st = read_chunk_head(ptr, avail, limit, dlen);
-    if (st) return st;
-    const uint32_t n = *dlen;
-    // container.rs:79-84: digest over type | data = ptr[4 .. 8+n), finalized
-    const uint32_t crc =
-        wave_crc(ptr + 4, 4ull + n, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
-    return crc == be32(ptr + 8 + n) ? 0u : 5u;    // :60-63
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Batch kernel.  A wave takes W consecutive items at a time (W = 1 .. 64, chosen
+// by the host so that every wave of the chip has work), ONE ITEM PER LANE for
+// everything that is not the CRC itself:
+//   A. lane j reads item j's descriptor and, in the chunk modes, its header
+//      (length, type, stored crc) and runs the checks that precede the CRC in the
+//      reference (container.rs:48-60, :109-113): descriptor and header latency is
+//      paid once per W items, not once per item;
+//   B. the CRC spans, by length:  under 32 bytes   one lane each, 64 at a time
+//                                 32 .. 240 bytes  one 16-lane group each, 4 at a time
+//                                 up to wave_max   the whole wave, one at a time
+//                                 longer           filed for the piece kernel
+//   C. lane j turns its item's registers into the verdict and stores it.
+// MODE is BatchArgs::verify.  In the document mode an item has two spans (AMRG
+// chunk, SEND chunk); the SEND span is done first so that a long AMRG chunk can
+// be filed with everything that follows its CRC check already decided.
+namespace {
+
+constexpr uint32_t kTinyMax = 31, kGroupMax = 240;
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
+}
+
+// The spans `slot` of this wave's items: registers over the whole span into `res`
+// (lanes with want == true), except for lanes whose span was filed (`filed`).
+// `may_file`: long spans may go to the piece kernel (primary span only).
+template <int MODE>
+__device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_t sp, uint64_t sl,
+                                          uint32_t item, uint32_t cont, uint32_t dlen, bool may_file,
+                                          uint32_t& res, bool& filed, const uint32_t* ldsY,
+                                          const uint32_t* ldsX, uint32_t lane, uint32_t lane32,
+                                          uint32_t aw, uint32_t aw16) {
+    const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
+    // under 32 bytes: a lane each
+    const bool tiny = want && sl <= (uint64_t)kTinyMax;
+    if (__any(tiny)) {
+        const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny);
+        if (tiny) res = r;
+    }
+    // 32 .. 240 bytes: a 16-lane group each, four at a time
+    unsigned long long m = __ballot(want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax);
+    while (m) {
+        int src[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            src[q] = m ? (int)__builtin_ctzll(m) : -1;
+            if (m) m &= m - 1;
+        }
+        const int q = (int)(lane >> 4);
+        const int mine = q == 0 ? src[0] : q == 1 ? src[1] : q == 2 ? src[2] : src[3];
+        const bool on = mine >= 0;
+        const uint64_t p = shfl64(sp, on ? mine : 0);
+        const uint32_t l = __shfl((uint32_t)sl, on ? mine : 0, 64);
+        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsX, lane, aw16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t v = __shfl(r, 16 * k, 64);
+            if (src[k] >= 0 && (int)lane == src[k]) res = v;
+        }
+    }
+    // longer: the whole wave, one at a time -- or filed for the piece kernel
+    m = __ballot(want && sl > (uint64_t)kGroupMax);
+    while (m) {
+        const int s = (int)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, s));
+        const uint64_t l = shfl64(sl, s);
+        if (may_file && file_span(b, __shfl(item, s, 64), p, l, __shfl(cont, s, 64), __shfl(dlen, s, 64), lane)) {
+            if ((int)lane == s) filed = true;
+            continue;
+        }
+        const uint32_t r = wave_crc(p, l, state, ldsY, ldsX, lane, lane32, aw);
+        if ((int)lane == s) res = r;
+    }
 }
 
 }  // namespace
 
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     __shared__ uint32_t lds[kYWords + kXWords];
     uint32_t* ldsY = lds;
@@ -607,114 +736,115 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 #pragma unroll 16
     for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kReplLog2];
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
-    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
+    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];            // x^(128 * (63 - lane))
+    const uint32_t aw16 = b.tabs->Kt[kThreads - 16 + (lane & 15u)];  // x^(128 * (15 - lane % 16))
     __syncthreads();
 
-    const uint32_t wave = blockIdx.x * (uint32_t)kWaves + (tid >> 6);
-    const uint32_t nwaves = gridDim.x * (uint32_t)kWaves;
-    for (uint32_t i = wave; i < b.n; i += nwaves) {
-        struct {
-            uint64_t offset, len;
-        } const it = {b.offsets[i], b.lens[i]};
-        const uint8_t* ptr = b.base + it.offset;
-        if (!b.verify) {
-            // crc.rs:28-34 on buffer i
-            if (file_span(b, i, ptr, it.len, 0u, 0u, lane)) continue;
-            const uint32_t r = wave_crc(ptr, it.len, b.state, ldsY, ldsX, lane, lane32, aw);
-            if (lane == 0) b.out[i] = r ^ b.xor_out;
-            continue;
-        }
-        if (b.verify == 3) {
-            // Chunk::write's last step x n (container.rs:75): the serialized chunk at
-            // ptr already holds length | type | data; compute the CRC over type | data
-            // and store it big-endian behind the data.  it.len = bytes of the slot.
-            uint32_t status = 0, dlen = 0;
-            if (it.len < 12u) {
-                status = 2;  // Error::Write: no room
-            } else {
-                dlen = be32(ptr);
-                if (it.len < 12ull + (uint64_t)dlen) status = 2;
-            }
-            if (status == 0) {
-                if (file_span(b, i, ptr + 4, 4ull + dlen, 0u, dlen, lane)) continue;
-                const uint32_t crc =
-                    wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
-                if (lane < 4u)
-                    const_cast<uint8_t*>(ptr)[8ull + dlen + lane] = (uint8_t)(crc >> (24u - 8u * lane));
-            }
-            if (lane == 0) {
-                b.out[i] = status;
-                if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
-            }
-            continue;
-        }
-        if (b.verify == 1) {
-            // Chunk::read x n
-            uint32_t dlen = 0;
-            uint32_t status = read_chunk_head(ptr, it.len, b.chunk_limit, &dlen);
-            if (status == 0) {
-                if (file_span(b, i, ptr + 4, 4ull + dlen, 0u, dlen, lane)) continue;
-                const uint32_t crc =
-                    wave_crc(ptr + 4, 4ull + dlen, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
-                if (crc != be32(ptr + 8 + dlen)) status = 5;  // :60-63
-            }
-            if (lane == 0) {
-                b.out[i] = status;
-                if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
-            }
-            continue;
-        }
-        // read_document's framing (document.rs:62-77): header, a chunk that must
-        // be AMRG, a chunk that must be SEND.  Each read_chunk verifies its CRC
-        // before expect_type looks at the type, as in the reference.
-        uint32_t status = 0, amrg_len = 0, dlen = 0;
-        uint64_t pos = 0;
-        if (it.len < 9u) {
-            status = 1;  // read_exact on the header fails (container.rs:109)
-        } else {
-            const uint8_t magic[9] = {0x89, 0x53, 0x49, 0x46, 0x54, 0x0D, 0x0A, 0x1A, 0x0A};
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (ptr[k] != magic[k]) status = 1;  // InvalidData (container.rs:113)
-            pos = 9;
-        }
-        bool amrg_filed = false;
-        if (status == 0) {
-            status = read_chunk_head(ptr + pos, it.len - pos, b.chunk_limit, &dlen);
-            amrg_len = dlen;
-            const uint64_t span = 4ull + dlen;
-            if (status == 0 && b.cut.counts && span > (uint64_t)b.cut.wave_max) {
-                // A long AMRG chunk goes to the piece kernel.  Everything the
-                // reference does AFTER that chunk's CRC check is decided here, so the
-                // finisher only has to pick: CRC bad -> 5, else this verdict.
-                uint32_t cont = be32(ptr + pos + 4) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
-                if (cont == 0) {
-                    const uint64_t p2 = pos + 12ull + dlen;
-                    uint32_t d2 = 0;
-                    cont = read_chunk_wave(ptr + p2, it.len - p2, b.chunk_limit, &d2, ldsY, ldsX,
-                                           lane, lane32, aw);
-                    if (cont == 0 && be32(ptr + p2 + 4) != 0x53454E44u) cont = 1;  // expect_type(SEND)
+    const uint32_t W = b.items_per_wave;
+    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (tid >> 6);
+    const uint64_t step = (uint64_t)gridDim.x * kWaves * W;
+    for (uint64_t first = wave * W; first < (uint64_t)b.n; first += step) {
+        const bool have = lane < W && first + lane < (uint64_t)b.n;
+        const uint32_t i = (uint32_t)(first + lane);
+
+        // ---- A: descriptor, header, the checks that come before the CRC ----
+        uint32_t status = 0, dlen = 0;        // status != 0: verdict already known
+        bool span0 = false, span1 = false;    // CRC spans still to do
+        uint64_t p0 = 0, l0 = 0, p1 = 0, l1 = 0;
+        uint32_t want0 = 0, want1 = 0;        // stored crcs
+        uint32_t cont = 0;                    // MODE 2: what the AMRG chunk's type says (1 = wrong type)
+        uint32_t st2 = 0, type1_bad = 0;      // MODE 2: SEND chunk
+        const uint8_t* ptr = b.base;
+        if (have) {
+            const uint64_t off = b.offsets[i], avail = b.lens[i];
+            ptr = b.base + off;
+            if (MODE == 0) {  // crc.rs:28-34 on buffer i
+                span0 = true;
+                p0 = reinterpret_cast<uint64_t>(ptr);
+                l0 = avail;
+            } else if (MODE == 1) {  // Chunk::read, container.rs:47-66
+                status = read_chunk_head(ptr, avail, b.chunk_limit, &dlen);
+                if (status == 0) {
+                    span0 = true;
+                    p0 = reinterpret_cast<uint64_t>(ptr + 4);
+                    l0 = 4ull + dlen;
+                    want0 = be32(ptr + 8 + dlen);
                 }
-                amrg_filed = file_span(b, i, ptr + pos + 4, span, cont, dlen, lane);
-            }
-            if (status == 0 && !amrg_filed) {
-                const uint32_t crc =
-                    wave_crc(ptr + pos + 4, span, 0xFFFFFFFFu, ldsY, ldsX, lane, lane32, aw) ^ 0xFFFFFFFFu;
-                if (crc != be32(ptr + pos + 8 + dlen)) status = 5;
-                if (status == 0 && be32(ptr + pos + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
-                pos += 12ull + dlen;
+            } else if (MODE == 3) {  // Chunk::write's crc step, container.rs:75; avail = bytes of the slot
+                if (avail < 12u) {
+                    status = 2;  // Error::Write: no room
+                } else {
+                    dlen = be32(ptr);
+                    if (avail < 12ull + (uint64_t)dlen) status = 2;
+                }
+                if (status == 0) {
+                    span0 = true;
+                    p0 = reinterpret_cast<uint64_t>(ptr + 4);
+                    l0 = 4ull + dlen;
+                }
+            } else {  // read_document's framing, document.rs:62-77
+                if (avail < 9u) {
+                    status = 1;  // read_exact on the header fails (container.rs:109)
+                } else {
+                    const uint8_t magic[9] = {0x89, 0x53, 0x49, 0x46, 0x54, 0x0D, 0x0A, 0x1A, 0x0A};
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        if (ptr[k] != magic[k]) status = 1;  // InvalidData (container.rs:113)
+                }
+                if (status == 0) status = read_chunk_head(ptr + 9, avail - 9, b.chunk_limit, &dlen);
+                if (status == 0) {
+                    span0 = true;
+                    p0 = reinterpret_cast<uint64_t>(ptr + 13);
+                    l0 = 4ull + dlen;
+                    want0 = be32(ptr + 17 + dlen);
+                    cont = be32(ptr + 13) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
+                    // the SEND chunk starts right behind; whether it is reached at all is
+                    // decided in C, in the reference's order
+                    const uint64_t pos2 = 21ull + dlen;
+                    uint32_t d2 = 0;
+                    st2 = read_chunk_head(ptr + pos2, avail - pos2, b.chunk_limit, &d2);
+                    if (st2 == 0) {
+                        span1 = true;
+                        p1 = reinterpret_cast<uint64_t>(ptr + pos2 + 4);
+                        l1 = 4ull + d2;
+                        want1 = be32(ptr + pos2 + 8 + d2);
+                        type1_bad = be32(ptr + pos2 + 4) != 0x53454E44u ? 1u : 0u;  // expect_type(SEND)
+                    }
+                }
             }
         }
-        if (amrg_filed) continue;
+
+        // ---- B: the CRCs ----
+        uint32_t r0 = 0, r1 = 0;
+        bool filed = false, never = false;
+        if (MODE == 2) {
+            crc_spans<MODE>(b, span1, p1, l1, i, 0u, 0u, false, r1, never, ldsY, ldsX, lane, lane32, aw, aw16);
+            // everything the reference does after the AMRG chunk's CRC check (document.rs:65-74)
+            if (cont == 0) cont = st2 ? st2 : ((r1 ^ 0xFFFFFFFFu) != want1 ? 5u : type1_bad);
+        }
+        crc_spans<MODE>(b, span0, p0, l0, i, cont, dlen, b.cut.counts != nullptr, r0, filed, ldsY, ldsX, lane,
+                        lane32, aw, aw16);
+
+        // ---- C: the verdict ----
+        if (!have || filed) continue;
+        if (MODE == 0) {
+            b.out[i] = r0 ^ b.xor_out;
+            continue;
+        }
+        const uint32_t crc = r0 ^ 0xFFFFFFFFu;  // container.rs:83
         if (status == 0) {
-            status = read_chunk_wave(ptr + pos, it.len - pos, b.chunk_limit, &dlen, ldsY, ldsX, lane,
-                                     lane32, aw);
-            if (status == 0 && be32(ptr + pos + 4) != 0x53454E44u) status = 1;  // expect_type(SEND)
+            if (MODE == 3) {
+                uint8_t* slot = const_cast<uint8_t*>(ptr) + 8ull + dlen;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
+            } else if (crc != want0) {
+                status = 5;  // container.rs:60-63
+            } else if (MODE == 2) {
+                status = cont;
+            }
         }
-        if (lane == 0) {
-            b.out[i] = status;
-            if (b.data_len) b.data_len[i] = status == 0 ? amrg_len : 0u;
-        }
+        b.out[i] = status;
+        if (b.data_len) b.data_len[i] = status == 0 ? dlen : 0u;
     }
 }
 
@@ -1107,8 +1237,13 @@ void launch_clear(uint32_t* words, int n, void* stream) {
 }
 
 void launch_batch(const BatchArgs& b, int groups, void* stream) {
-    hipLaunchKernelGGL(crc32_batch_kernel, dim3(groups), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), b);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (b.verify) {
+        case 0: hipLaunchKernelGGL(crc32_batch_kernel<0>, dim3(groups), dim3(kThreads), 0, s, b); break;
+        case 1: hipLaunchKernelGGL(crc32_batch_kernel<1>, dim3(groups), dim3(kThreads), 0, s, b); break;
+        case 2: hipLaunchKernelGGL(crc32_batch_kernel<2>, dim3(groups), dim3(kThreads), 0, s, b); break;
+        default: hipLaunchKernelGGL(crc32_batch_kernel<3>, dim3(groups), dim3(kThreads), 0, s, b); break;
+    }
 }
 
 void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream) {
