@@ -253,6 +253,9 @@ void build_tables(DeviceTables* t) {
     const uint32_t y1 = gf2_xpow(x2n(), 8ull * 1024);
     for (int k = 0; k < 4; ++k)
         for (uint32_t b = 0; b < 256; ++b) t->Y1[k * 256 + b] = gf2_mulmod(b << (8 * k), y1);
+    const uint32_t y256 = gf2_xpow(x2n(), 8ull * 256);
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t b = 0; b < 256; ++b) t->Y256[k * 256 + b] = gf2_mulmod(b << (8 * k), y256);
     uint32_t c1 = gf2_xpow(x2n(), 128ull * kThreads);
     for (int i = 0; i < 32; ++i) {
         t->C1[i] = c1;

@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t mul_y(uint32_t a, const uint32_t* ldsY, uint
 }
 
 // v * x^32: the reference's table step applied to four bytes at once.
-__device__ __forceinline__ uint32_t mul_x32(uint32_t v, const uint32_t* ldsX) {
+template <typename P>
+__device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
     return ldsX[v & 0xffu] ^ ldsX[256 + ((v >> 8) & 0xffu)] ^ ldsX[512 + ((v >> 16) & 0xffu)] ^
            ldsX[768 + (v >> 24)];
 }
@@ -487,31 +488,82 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     return r;
 }
 
-// CRC of a span of 32..240 bytes by ONE 16-LANE GROUP: a 16-byte vector per lane,
-// so the span's body (at most 16 vectors) is a single tile and there is no Horner
-// step: fold the four words, weight by the lane's place, XOR over the group.
-// Four spans per wave at a time.  Every lane of the wave calls this; `on` says
-// whether the lane's group has a span.  The register over the whole span comes
-// back in every lane of the group.
-__device__ __forceinline__ uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
-                                              const uint32_t* ldsX, uint32_t lane, uint32_t aw16) {
-    const uint32_t l16 = lane & 15u, gbase = lane & 48u;
+// acc * x^(8*256): the group path's Horner constant.  The table is replicated four
+// times only (LDS has 28 KiB left beside the wave path's): entry (k, b) for copy r
+// lives at word ((k*256 + b) * 4 + r), lane l uses r = l & 3.  Lookups conflict
+// about two ways on average, which this latency-bound path does not notice.
+template <typename P>
+__device__ __forceinline__ uint32_t mul_yg(uint32_t a, P ldsG, uint32_t l4) {
+    constexpr int T = 256 * kGroupRepl;
+    const uint32_t i0 = ((a & 0xffu) << kGroupReplLog2) + l4;
+    const uint32_t i1 = (((a >> 8) & 0xffu) << kGroupReplLog2) + l4;
+    const uint32_t i2 = (((a >> 16) & 0xffu) << kGroupReplLog2) + l4;
+    const uint32_t i3 = ((a >> 24) << kGroupReplLog2) + l4;
+    return ldsG[i0] ^ ldsG[T + i1] ^ ldsG[2 * T + i2] ^ ldsG[3 * T + i3];
+}
+
+template <typename P>
+__device__ __forceinline__ void horner_g(u32x4& acc, const u32x4 w, P ldsG, uint32_t l4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = mul_yg(acc[c], ldsG, l4) ^ w[c];
+}
+
+// CRC of a span of 32 .. kGroupMax bytes by ONE 16-LANE GROUP, four spans per wave
+// at a time: the wave kernel's algebra at group scale.  A tile is 16 lanes x 16 B
+// = 256 B, the Horner step multiplies by x^(8*256), tiles are aligned to the end
+// of the body so only the first can be partial.  Every lane of the wave calls
+// this; `on` says whether the lane's group has a span.  The register over the
+// whole span comes back in every lane of the group.  Not inlined: inside the batch
+// kernel's item loop, beside the wave path, it pushed the kernel past 128 VGPRs
+// (15-43 spilled); as a call it costs a few instructions per four spans.
+__device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+                                              const uint32_t* ldsG_, const uint32_t* ldsX_, uint32_t lane,
+                                              uint32_t aw16) {
+    // A call passes generic pointers; say which memory they point into, or every
+    // table lookup becomes a flat load that waits on both counters.
+    typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
+    typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
+    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
+    const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_;
+    const uint32_t l16 = lane & 15u, gbase = lane & 48u, l4 = lane & (uint32_t)(kGroupRepl - 1);
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
-    const int32_t nvec = (int32_t)(v1 - v0);  // 2..16 for 32 <= len <= 240
+    const int32_t nvec = (int32_t)(v1 - v0);  // 2..255
     const uint32_t h = (uint32_t)(addr & 15u);
-    const int32_t vi = nvec - 16 + (int32_t)l16;  // the tile is aligned to the end of the body
+    const GlobalVec vbase = (GlobalVec)(v0 << 4);
+    const int32_t ntile = on ? (nvec + 15) >> 4 : 0;
+    int32_t vi = nvec - ntile * 16 + (int32_t)l16;
     const uint32_t tail_len = on ? (uint32_t)((addr + len) & 15u) : 0u;
-    u32x4 acc = {0u, 0u, 0u, 0u};
+    // Tile 0 (may start before vector 0) and tile 1 are peeled: the four state bytes
+    // land in vectors 0 and 1.
+    u32x4 acc = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
     uint32_t tb = 0;
     if (on) {
-        if (vi >= 0) acc = reinterpret_cast<const u32x4*>(v0 << 4)[vi];
-        if (l16 < tail_len) tb = reinterpret_cast<const uint8_t*>(v1 << 4)[l16];
+        if (vi >= 0) acc = vbase[vi];
+        if (ntile > 1) w1 = vbase[vi + 16];
+        if (l16 < tail_len) tb = ((GlobalByte)(v1 << 4))[l16];
         if (vi >= 0) {
             if (vi == 0 && h) acc = mask_head(acc, h);
             acc = fold_state(acc, vi, h, state);
         }
+        if (ntile > 1) {
+            w1 = fold_state(w1, vi + 16, h, state);
+            horner_g(acc, w1, ldsG, l4);
+        }
     }
+    vi += 32;
+    // the rest two tiles at a time; groups with fewer tiles sit the iterations out
+    for (int32_t t = 2; __any(t < ntile); t += 2, vi += 32) {
+        u32x4 wa = {0u, 0u, 0u, 0u}, wb = {0u, 0u, 0u, 0u};
+        const bool ha = t < ntile, hb = t + 1 < ntile;
+        if (ha) wa = __builtin_nontemporal_load(vbase + vi);
+        if (hb) wb = __builtin_nontemporal_load(vbase + vi + 16);
+        if (ha) horner_g(acc, wa, ldsG, l4);
+        if (hb) horner_g(acc, wb, ldsG, l4);
+    }
+    // (four register multiplies by per-lane constants instead of the x^32 table and
+    // one multiply were tried: 1.9x slower -- this path is VALU-bound, a wave64
+    // instruction takes four cycles)
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
@@ -654,17 +706,17 @@ __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t
 //      (length, type, stored crc) and runs the checks that precede the CRC in the
 //      reference (container.rs:48-60, :109-113): descriptor and header latency is
 //      paid once per W items, not once per item;
-//   B. the CRC spans, by length:  under 32 bytes   one lane each, 64 at a time
-//                                 32 .. 240 bytes  one 16-lane group each, 4 at a time
-//                                 up to wave_max   the whole wave, one at a time
-//                                 longer           filed for the piece kernel
+//   B. the CRC spans, by length:  under 32 bytes    one lane each, 64 at a time
+//                                 32 .. 4080 bytes  one 16-lane group each, 4 at a time
+//                                 up to wave_max    the whole wave, one at a time
+//                                 longer            filed for the piece kernel
 //   C. lane j turns its item's registers into the verdict and stores it.
 // MODE is BatchArgs::verify.  In the document mode an item has two spans (AMRG
 // chunk, SEND chunk); the SEND span is done first so that a long AMRG chunk can
 // be filed with everything that follows its CRC check already decided.
 namespace {
 
-constexpr uint32_t kTinyMax = 31, kGroupMax = 240;
+constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16 group tiles
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
@@ -677,8 +729,8 @@ template <int MODE>
 __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_t sp, uint64_t sl,
                                           uint32_t item, uint32_t cont, uint32_t dlen, bool may_file,
                                           uint32_t& res, bool& filed, const uint32_t* ldsY,
-                                          const uint32_t* ldsX, uint32_t lane, uint32_t lane32,
-                                          uint32_t aw, uint32_t aw16) {
+                                          const uint32_t* ldsG, const uint32_t* ldsX, uint32_t lane,
+                                          uint32_t lane32, uint32_t aw, uint32_t aw16) {
     const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
     // under 32 bytes: a lane each
     const bool tiny = want && sl <= (uint64_t)kTinyMax;
@@ -686,7 +738,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny);
         if (tiny) res = r;
     }
-    // 32 .. 240 bytes: a 16-lane group each, four at a time
+    // 32 .. 4080 bytes: a 16-lane group each, four at a time
     unsigned long long m = __ballot(want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax);
     while (m) {
         int src[4];
@@ -700,7 +752,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const bool on = mine >= 0;
         const uint64_t p = shfl64(sp, on ? mine : 0);
         const uint32_t l = __shfl((uint32_t)sl, on ? mine : 0, 64);
-        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsX, lane, aw16);
+        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX, lane, aw16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t v = __shfl(r, 16 * k, 64);
@@ -727,14 +779,17 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
-    __shared__ uint32_t lds[kYWords + kXWords];
+    constexpr int kGWords = 4 * 256 * kGroupRepl;
+    __shared__ uint32_t lds[kYWords + kGWords + kXWords];
     uint32_t* ldsY = lds;
-    uint32_t* ldsX = lds + kYWords;
+    uint32_t* ldsG = lds + kYWords;
+    uint32_t* ldsX = ldsG + kGWords;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
 #pragma unroll 16
     for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kReplLog2];
+    for (int i = tid; i < kGWords; i += kThreads) ldsG[i] = b.tabs->Y256[i >> kGroupReplLog2];
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
     const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];            // x^(128 * (63 - lane))
     const uint32_t aw16 = b.tabs->Kt[kThreads - 16 + (lane & 15u)];  // x^(128 * (15 - lane % 16))
@@ -748,28 +803,22 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         const uint32_t i = (uint32_t)(first + lane);
 
         // ---- A: descriptor, header, the checks that come before the CRC ----
-        uint32_t status = 0, dlen = 0;        // status != 0: verdict already known
-        bool span0 = false, span1 = false;    // CRC spans still to do
-        uint64_t p0 = 0, l0 = 0, p1 = 0, l1 = 0;
-        uint32_t want0 = 0, want1 = 0;        // stored crcs
-        uint32_t cont = 0;                    // MODE 2: what the AMRG chunk's type says (1 = wrong type)
-        uint32_t st2 = 0, type1_bad = 0;      // MODE 2: SEND chunk
+        // Kept per lane across the CRCs: the item's address, its data length(s) and
+        // what the checks said; stored crcs and chunk types are read again in C.
+        uint32_t status = 0, dlen = 0;      // status != 0: verdict already known
+        uint32_t st2 = 0, d2 = 0;           // MODE 2: the SEND chunk's checks and data length
+        uint64_t len0 = 0;                  // MODE 0: the buffer's length
+        bool span0 = false, span1 = false;  // CRC spans still to do
         const uint8_t* ptr = b.base;
         if (have) {
             const uint64_t off = b.offsets[i], avail = b.lens[i];
             ptr = b.base + off;
             if (MODE == 0) {  // crc.rs:28-34 on buffer i
                 span0 = true;
-                p0 = reinterpret_cast<uint64_t>(ptr);
-                l0 = avail;
+                len0 = avail;
             } else if (MODE == 1) {  // Chunk::read, container.rs:47-66
                 status = read_chunk_head(ptr, avail, b.chunk_limit, &dlen);
-                if (status == 0) {
-                    span0 = true;
-                    p0 = reinterpret_cast<uint64_t>(ptr + 4);
-                    l0 = 4ull + dlen;
-                    want0 = be32(ptr + 8 + dlen);
-                }
+                span0 = status == 0;
             } else if (MODE == 3) {  // Chunk::write's crc step, container.rs:75; avail = bytes of the slot
                 if (avail < 12u) {
                     status = 2;  // Error::Write: no room
@@ -777,11 +826,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                     dlen = be32(ptr);
                     if (avail < 12ull + (uint64_t)dlen) status = 2;
                 }
-                if (status == 0) {
-                    span0 = true;
-                    p0 = reinterpret_cast<uint64_t>(ptr + 4);
-                    l0 = 4ull + dlen;
-                }
+                span0 = status == 0;
             } else {  // read_document's framing, document.rs:62-77
                 if (avail < 9u) {
                     status = 1;  // read_exact on the header fails (container.rs:109)
@@ -794,36 +839,49 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 if (status == 0) status = read_chunk_head(ptr + 9, avail - 9, b.chunk_limit, &dlen);
                 if (status == 0) {
                     span0 = true;
-                    p0 = reinterpret_cast<uint64_t>(ptr + 13);
-                    l0 = 4ull + dlen;
-                    want0 = be32(ptr + 17 + dlen);
-                    cont = be32(ptr + 13) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
                     // the SEND chunk starts right behind; whether it is reached at all is
                     // decided in C, in the reference's order
                     const uint64_t pos2 = 21ull + dlen;
-                    uint32_t d2 = 0;
                     st2 = read_chunk_head(ptr + pos2, avail - pos2, b.chunk_limit, &d2);
-                    if (st2 == 0) {
-                        span1 = true;
-                        p1 = reinterpret_cast<uint64_t>(ptr + pos2 + 4);
-                        l1 = 4ull + d2;
-                        want1 = be32(ptr + pos2 + 8 + d2);
-                        type1_bad = be32(ptr + pos2 + 4) != 0x53454E44u ? 1u : 0u;  // expect_type(SEND)
-                    }
+                    span1 = st2 == 0;
                 }
             }
         }
+        // where the spans are: type | data of the chunk at `at` (container.rs:79-84)
+        constexpr uint32_t kChunkAt = MODE == 2 ? 9u : 0u;  // first chunk, from the item's start
+        const uint8_t* send = ptr + 21ull + dlen;           // MODE 2: the second chunk
 
-        // ---- B: the CRCs ----
+        // ---- B: the CRCs ----  (one instance of the span code: the document mode
+        // runs it twice, SEND span first)
         uint32_t r0 = 0, r1 = 0;
-        bool filed = false, never = false;
-        if (MODE == 2) {
-            crc_spans<MODE>(b, span1, p1, l1, i, 0u, 0u, false, r1, never, ldsY, ldsX, lane, lane32, aw, aw16);
-            // everything the reference does after the AMRG chunk's CRC check (document.rs:65-74)
-            if (cont == 0) cont = st2 ? st2 : ((r1 ^ 0xFFFFFFFFu) != want1 ? 5u : type1_bad);
+        bool filed = false;
+        for (int slot = MODE == 2 ? 1 : 0; slot >= 0; --slot) {
+            uint32_t r = 0, cont = 0;
+            bool f = false;
+            const uint8_t* sp = MODE == 0 ? ptr : (slot ? send + 4 : ptr + kChunkAt + 4);
+            const uint64_t sl = MODE == 0 ? len0 : 4ull + (slot ? d2 : dlen);
+            const bool may_file = slot == 0 && b.cut.counts != nullptr;
+            if (MODE == 2 && may_file && __any(span0 && sl > (uint64_t)b.cut.wave_max)) {
+                // A long AMRG chunk goes to the piece kernel with everything the reference
+                // does AFTER that chunk's CRC check (document.rs:65-74) already decided.
+                if (span0) {
+                    cont = be32(ptr + 13) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
+                    if (cont == 0)
+                        cont = st2 ? st2
+                                   : ((r1 ^ 0xFFFFFFFFu) != be32(send + 8 + d2) ? 5u
+                                      : be32(send + 4) != 0x53454E44u        ? 1u
+                                                                              : 0u);
+                }
+            }
+            crc_spans<MODE>(b, slot ? span1 : span0, reinterpret_cast<uint64_t>(sp), sl, i, cont, dlen, may_file,
+                            r, f, ldsY, ldsG, ldsX, lane, lane32, aw, aw16);
+            if (slot) {
+                r1 = r;
+            } else {
+                r0 = r;
+                filed = f;
+            }
         }
-        crc_spans<MODE>(b, span0, p0, l0, i, cont, dlen, b.cut.counts != nullptr, r0, filed, ldsY, ldsX, lane,
-                        lane32, aw, aw16);
 
         // ---- C: the verdict ----
         if (!have || filed) continue;
@@ -831,16 +889,20 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             b.out[i] = r0 ^ b.xor_out;
             continue;
         }
-        const uint32_t crc = r0 ^ 0xFFFFFFFFu;  // container.rs:83
         if (status == 0) {
+            const uint8_t* chunk = ptr + kChunkAt;
+            const uint32_t crc = r0 ^ 0xFFFFFFFFu;  // container.rs:83
             if (MODE == 3) {
-                uint8_t* slot = const_cast<uint8_t*>(ptr) + 8ull + dlen;
+                uint8_t* slot = const_cast<uint8_t*>(chunk) + 8ull + dlen;
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
-            } else if (crc != want0) {
+            } else if (crc != be32(chunk + 8ull + dlen)) {
                 status = 5;  // container.rs:60-63
             } else if (MODE == 2) {
-                status = cont;
+                if (be32(chunk + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
+                else if (st2) status = st2;                      // read_chunk on the SEND chunk, before its crc
+                else if ((r1 ^ 0xFFFFFFFFu) != be32(send + 8ull + d2)) status = 5;
+                else if (be32(send + 4) != 0x53454E44u) status = 1;  // expect_type(SEND)
             }
         }
         b.out[i] = status;
