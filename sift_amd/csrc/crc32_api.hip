@@ -256,6 +256,12 @@ void build_tables(DeviceTables* t) {
     const uint32_t y256 = gf2_xpow(x2n(), 8ull * 256);
     for (int k = 0; k < 4; ++k)
         for (uint32_t b = 0; b < 256; ++b) t->Y256[k * 256 + b] = gf2_mulmod(b << (8 * k), y256);
+    for (uint32_t b = 0; b < 256; ++b) t->T8[b] = crc_step_byte(0u, b);
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t kj = gf2_xpow(x2n(), 128ull << j);
+        for (int k = 0; k < 4; ++k)
+            for (uint32_t b = 0; b < 256; ++b) t->K[j][k * 256 + b] = gf2_mulmod(b << (8 * k), kj);
+    }
     uint32_t c1 = gf2_xpow(x2n(), 128ull * kThreads);
     for (int i = 0; i < 32; ++i) {
         t->C1[i] = c1;

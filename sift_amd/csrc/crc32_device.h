@@ -43,8 +43,8 @@ constexpr int kUnroll = SIFT_UNROLL;        // tiles in flight per lane, twice (
 constexpr int kGroupsPerCu = SIFT_GROUPS_PER_CU;  // resident workgroups per CU the LDS budget allows
 static_assert(kReplLog2 > 0, "SIFT_REPL must be 8, 16 or 32");
 static_assert(kThreads % 64 == 0 && kThreads >= 64 && kThreads <= 1024, "SIFT_THREADS");
-constexpr int kGroupRepl = 4;                // LDS copies of the batch kernel's group-path table
-constexpr int kGroupReplLog2 = 2;
+constexpr int kGroupRepl = 2;                // LDS copies of the batch kernel's group-path Horner table
+constexpr int kGroupReplLog2 = 1;
 constexpr int kMaxGroups = 1024;            // workgroups one call may launch
 constexpr int kTreeLevels = 10;             // log2(kMaxGroups)
 
@@ -57,6 +57,9 @@ struct DeviceTables {
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
     uint32_t Y256[4 * 256];  // Y256[k*256+b] = (b << 8k) * x^(8*256) mod P  (16-lane group tiles, batch kernel)
+    uint32_t T8[256];        // T8[b] = b * x^8 mod P: the reference's CRC_TABLE itself (crc.rs:2-20), for
+                             // bytes that are walked one at a time (tails, spans under 32 bytes)
+    uint32_t K[4][4 * 256];  // K[j][k*256+b] = (b << 8k) * x^(128 * 2^j): joins neighbouring lanes' residues
     uint32_t C1[32];         // C1[i] = x^(128*kThreads) * x^i: from one of a lane's vectors to its next
     uint32_t X2[32][32];     // X2[s][k] = x^(2^s) * x^k: row k of the matrix of x^(2^s) (piece weights)
     uint32_t XinvH[16];      // XinvH[h] = x^(-8h): folds a starting register into a vector with h pad bytes

@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
            ldsX[768 + (v >> 24)];
 }
 
+// One byte of the reference's recurrence WITH its table (crc.rs:31):
+// c = CRC_TABLE[(c ^ byte) & 0xff] ^ (c >> 8).
+template <typename P>
+__device__ __forceinline__ uint32_t table_step_byte(uint32_t c, uint32_t byte, P ldsT8) {
+    return ldsT8[(c ^ byte) & 0xffu] ^ (c >> 8);
+}
+
 // One Horner step for a lane's four words: acc <- acc * y + w.
 #ifndef SIFT_ABLATE_WORDS
 #define SIFT_ABLATE_WORDS 4  // timing-only builds thin the step to fewer real multiplies
@@ -428,7 +435,7 @@ __device__ __forceinline__ u32x4 fold_state(u32x4 w, int64_t vi, uint32_t h, uin
 }
 
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
-                                             const uint32_t* ldsY, const uint32_t* ldsX,
+                                             const uint32_t* ldsY, const uint32_t* ldsX, const uint32_t* ldsT8,
                                              uint32_t lane, uint32_t lane32, uint32_t aw) {
     if (len < 32u) {
         uint32_t r = state;
@@ -484,7 +491,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     r = gf2_mulmod(r, aw);
     r = wave_xor(r);
     // trailing bytes: every lane walks them alike (no divergence, no broadcast)
-    for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, __shfl(tb, (int)i, 64));
+    for (uint32_t i = 0; i < tail_len; ++i) r = table_step_byte(r, __shfl(tb, (int)i, 64), ldsT8);
     return r;
 }
 
@@ -513,18 +520,18 @@ __device__ __forceinline__ void horner_g(u32x4& acc, const u32x4 w, P ldsG, uint
 // = 256 B, the Horner step multiplies by x^(8*256), tiles are aligned to the end
 // of the body so only the first can be partial.  Every lane of the wave calls
 // this; `on` says whether the lane's group has a span.  The register over the
-// whole span comes back in every lane of the group.  Not inlined: inside the batch
+// whole span comes back in lane 0 of the group.  Not inlined: inside the batch
 // kernel's item loop, beside the wave path, it pushed the kernel past 128 VGPRs
 // (15-43 spilled); as a call it costs a few instructions per four spans.
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
-                                              const uint32_t* ldsG_, const uint32_t* ldsX_, uint32_t lane,
-                                              uint32_t aw16) {
+                                              const uint32_t* ldsG_, const uint32_t* ldsX_,
+                                              const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
     // A call passes generic pointers; say which memory they point into, or every
     // table lookup becomes a flat load that waits on both counters.
     typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
     typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
-    const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_;
+    const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
     const uint32_t l16 = lane & 15u, gbase = lane & 48u, l4 = lane & (uint32_t)(kGroupRepl - 1);
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
@@ -561,25 +568,31 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         if (ha) horner_g(acc, wa, ldsG, l4);
         if (hb) horner_g(acc, wb, ldsG, l4);
     }
-    // (four register multiplies by per-lane constants instead of the x^32 table and
-    // one multiply were tried: 1.9x slower -- this path is VALU-bound, a wave64
-    // instruction takes four cycles)
+    // the lane's four words, then the sixteen lanes joined pairwise: at step j the
+    // lane whose bit j is clear holds the earlier 2^j vectors, multiplies by
+    // x^(128 * 2^j) (four lookups in K[j]) and takes in its partner's.  Lane 0 of the
+    // group ends up with the body's register.  (A 32-step register multiply by the
+    // lane's place, x^(128 * (15 - lane)), costs 7 instructions a bit; this path is
+    // VALU-bound -- a wave64 instruction takes four cycles -- so lookups win.  Four
+    // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
-    r = gf2_mulmod(r, aw16);
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) r ^= __shfl_xor(r, off, 64);
+    for (int j = 0; j < 4; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
+    // trailing bytes, with the reference's own table; only lane 0 of a group holds a
+    // meaningful register, the others walk along
     for (uint32_t i = 0; __any(i < tail_len); ++i) {
         const uint32_t byte = __shfl(tb, (int)(gbase + i), 64);
-        if (i < tail_len) r = crc_step_byte(r, byte);
+        if (i < tail_len) r = table_step_byte(r, byte, ldsT8);
     }
     return r;
 }
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
-// bytes are fetched first, all at once, then walked with the bitwise recurrence.
-__device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on) {
+// bytes are fetched first, all at once, then walked with the reference's table step.
+__device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+                                             const uint32_t* ldsT8) {
     uint32_t r = state;
     on = on && len != 0u;
     uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -597,7 +610,7 @@ __device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr, uint32_t len, u
     if (on) {
 #pragma unroll
         for (uint32_t k = 0; k < 31u; ++k)
-            if (k < len) r = crc_step_byte(r, (w[k >> 2] >> (8u * (k & 3u))) & 0xffu);
+            if (k < len) r = table_step_byte(r, (w[k >> 2] >> (8u * (k & 3u))) & 0xffu, ldsT8);
     }
     return r;
 }
@@ -729,13 +742,13 @@ template <int MODE>
 __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_t sp, uint64_t sl,
                                           uint32_t item, uint32_t cont, uint32_t dlen, bool may_file,
                                           uint32_t& res, bool& filed, const uint32_t* ldsY,
-                                          const uint32_t* ldsG, const uint32_t* ldsX, uint32_t lane,
-                                          uint32_t lane32, uint32_t aw, uint32_t aw16) {
+                                          const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
+                                          const uint32_t* ldsT8, uint32_t lane, uint32_t lane32, uint32_t aw) {
     const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
     // under 32 bytes: a lane each
     const bool tiny = want && sl <= (uint64_t)kTinyMax;
     if (__any(tiny)) {
-        const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny);
+        const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, ldsT8);
         if (tiny) res = r;
     }
     // 32 .. 4080 bytes: a 16-lane group each, four at a time
@@ -752,7 +765,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const bool on = mine >= 0;
         const uint64_t p = shfl64(sp, on ? mine : 0);
         const uint32_t l = __shfl((uint32_t)sl, on ? mine : 0, 64);
-        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX, lane, aw16);
+        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t v = __shfl(r, 16 * k, 64);
@@ -770,7 +783,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             if ((int)lane == s) filed = true;
             continue;
         }
-        const uint32_t r = wave_crc(p, l, state, ldsY, ldsX, lane, lane32, aw);
+        const uint32_t r = wave_crc(p, l, state, ldsY, ldsX, ldsT8, lane, lane32, aw);
         if ((int)lane == s) res = r;
     }
 }
@@ -780,10 +793,13 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     constexpr int kGWords = 4 * 256 * kGroupRepl;
-    __shared__ uint32_t lds[kYWords + kGWords + kXWords];
+    constexpr int kKWords = 4 * 4 * 256, kT8Words = 256;
+    __shared__ uint32_t lds[kYWords + kGWords + kXWords + kKWords + kT8Words];  // 157 of 160 KiB
     uint32_t* ldsY = lds;
     uint32_t* ldsG = lds + kYWords;
     uint32_t* ldsX = ldsG + kGWords;
+    uint32_t* ldsK = ldsX + kXWords;
+    uint32_t* ldsT8 = ldsK + kKWords;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
@@ -791,8 +807,9 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kReplLog2];
     for (int i = tid; i < kGWords; i += kThreads) ldsG[i] = b.tabs->Y256[i >> kGroupReplLog2];
     for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
-    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];            // x^(128 * (63 - lane))
-    const uint32_t aw16 = b.tabs->Kt[kThreads - 16 + (lane & 15u)];  // x^(128 * (15 - lane % 16))
+    for (int i = tid; i < kKWords; i += kThreads) ldsK[i] = (&b.tabs->K[0][0])[i];
+    for (int i = tid; i < kT8Words; i += kThreads) ldsT8[i] = b.tabs->T8[i];
+    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
     __syncthreads();
 
     const uint32_t W = b.items_per_wave;
@@ -874,7 +891,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 }
             }
             crc_spans<MODE>(b, slot ? span1 : span0, reinterpret_cast<uint64_t>(sp), sl, i, cont, dlen, may_file,
-                            r, f, ldsY, ldsG, ldsX, lane, lane32, aw, aw16);
+                            r, f, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32, aw);
             if (slot) {
                 r1 = r;
             } else {

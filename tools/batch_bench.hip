@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     printf("{\"rows\": [\n");
     bool first = true;
     // plain buffers back to back in the blob, descriptors in HBM and on the host
-    const size_t sizes[] = {64, 1024, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
+    const size_t sizes[] = {64, 100, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
     for (size_t size : sizes) {
         if (only_chunk) break;
         const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
