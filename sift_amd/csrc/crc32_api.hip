@@ -1097,13 +1097,14 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     }
     b.offsets = static_cast<const uint64_t*>(dv_off);
     b.lens = static_cast<const uint64_t*>(dv_len);
-    // Items a wave takes at a time (one per lane): as few as still give every wave
-    // of the chip work, so that a small batch spreads over many waves and a big one
-    // pays descriptor and header latency once per 64 items.
+    // Items a wave takes at a time (one per lane): a big batch pays descriptor and
+    // header latency once per 64 items, a smaller one keeps about four turns per wave
+    // so that the chip stays balanced (items differ in length), a small one spreads
+    // one item per wave.
     const int waves_per_group = kThreads / 64;
     const uint64_t chip_waves = (uint64_t)c->groups_max * waves_per_group;
     uint32_t per_wave = 1;
-    while (per_wave < 64u && (uint64_t)per_wave * chip_waves < n) per_wave *= 2;
+    while (per_wave < 64u && (uint64_t)per_wave * 2 * 4 * chip_waves <= n) per_wave *= 2;
     b.items_per_wave = per_wave;
     const uint64_t wave_chunks = ((uint64_t)n + per_wave - 1) / per_wave;
     const int groups = (int)std::min<uint64_t>((wave_chunks + waves_per_group - 1) / waves_per_group,

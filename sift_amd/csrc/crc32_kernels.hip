@@ -474,12 +474,22 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
         p += 64;
         --left;
     }
-    for (; left >= 2; left -= 2) {
-        u32x4 w0 = __builtin_nontemporal_load(p);
-        u32x4 w1 = __builtin_nontemporal_load(p + 64);
+    if (left >= 2) {
+        // two tiles in flight while the two before them are folded
+        u32x4 c0 = __builtin_nontemporal_load(p);
+        u32x4 c1 = __builtin_nontemporal_load(p + 64);
         p += 128;
-        horner_step(acc, w0, ldsY, lane32);
-        horner_step(acc, w1, ldsY, lane32);
+        for (left -= 2; left >= 2; left -= 2) {
+            const u32x4 n0 = __builtin_nontemporal_load(p);
+            const u32x4 n1 = __builtin_nontemporal_load(p + 64);
+            p += 128;
+            horner_step(acc, c0, ldsY, lane32);
+            horner_step(acc, c1, ldsY, lane32);
+            c0 = n0;
+            c1 = n1;
+        }
+        horner_step(acc, c0, ldsY, lane32);
+        horner_step(acc, c1, ldsY, lane32);
     }
     if (left > 0) {
         const u32x4 w = __builtin_nontemporal_load(p);

@@ -142,6 +142,49 @@ int main(int argc, char** argv) {
         first = false;
         fflush(stdout);
     }
+    // read_document's framing on MANY small save files (header | AMRG chunk | SEND chunk),
+    // the shape of the reference's real data: one valid file built with the library's
+    // own host entry point, repeated back to back
+    if (!only_chunk) {
+        for (size_t payload : {(size_t)500, (size_t)2000, (size_t)8000}) {
+            std::vector<uint8_t> pl(payload), file(payload + 33);
+            for (size_t i = 0; i < payload; ++i) pl[i] = (uint8_t)(i * 131u + 7u);
+            const int64_t flen = sift_write_document(0, pl.data(), payload, file.data(), file.size());
+            if (flen != (int64_t)file.size()) return 5;
+            const size_t pitch = (file.size() + 15) & ~size_t(15);
+            const uint32_t n = (uint32_t)std::min<size_t>(total / pitch, 1 << 20);
+            std::vector<uint8_t> host((size_t)n * pitch, 0);
+            for (uint32_t i = 0; i < n; ++i) {
+                memcpy(host.data() + (size_t)i * pitch, file.data(), file.size());
+                off[i] = (uint64_t)i * pitch;
+                len[i] = file.size();
+            }
+            CK(hipMemcpy(blob, host.data(), host.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
+            for (int i = 0; i < 3; ++i) SK(sift_read_documents_device(0, blob, d_off, d_len, n, d_out, nullptr, s));
+            CK(hipStreamSynchronize(s));
+            std::vector<uint32_t> st(n);
+            CK(hipMemcpy(st.data(), d_out, 4ull * n, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; ++i)
+                if (st[i] != 0) {
+                    fprintf(stderr, "document %u: status %u\n", i, st[i]);
+                    return 6;
+                }
+            const int reps = 20;
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) SK(sift_read_documents_device(0, blob, d_off, d_len, n, d_out, nullptr, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf(",\n {\"kind\": \"read_documents\", \"descriptors\": \"device\", \"file_bytes\": %zu, \"files\": %u, "
+                   "\"device_us_per_call\": %.2f, \"Mfiles_per_s\": %.1f, \"GBps_device\": %.1f}",
+                   file.size(), n, ms * 1e3 / reps, n / (ms * 1e-3 / reps) / 1e6,
+                   (double)n * file.size() / (ms * 1e-3 / reps) / 1e9);
+            fflush(stdout);
+        }
+    }
     printf("\n]}\n");
     return 0;
 }
