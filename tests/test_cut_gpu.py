@@ -1,6 +1,6 @@
 """GPU parity for long items in the batch entry points: an item whose CRC span is
-long is cut on the device into pieces (one workgroup each) and finished by a
-third kernel.  Every verdict is compared with the oracle's Chunk::read /
+long is cut on the device into pieces that whole workgroups reduce; the piece
+that completes an item gives it its verdict.  Every verdict is compared with the oracle's Chunk::read /
 compute on the same bytes (container.rs:47-66, crc.rs:28-34), with the
 descriptors on the host and in HBM, for corrupted, truncated and oversize chunks.
 """
