@@ -216,8 +216,40 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 
     if (USE_Y) {
         if (batched) {
-            while (ntiles >= U) {
-                u32x4 nxt[U][kVpl];
+            // Two register sets take turns (cur is folded while nxt loads, then
+            // the other way round), so no batch is ever copied between registers.
+            u32x4 nxt[U][kVpl];
+            while (ntiles >= 2 * U) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j)
+                        nxt[u][j] = load_tile(srd, voff, soff + u * kTileBytes + j * kThreads * 16);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
+                // The batch before must have landed before the next one is asked
+                // for (one batch in flight per wave: two cost 3 % of HBM rate), and
+                // a batch's loads go out back to back.
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j)
+                        cur[u][j] = load_tile(srd, voff, soff + (U + u) * kTileBytes + j * kThreads * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                soff += 2 * U * kTileBytes;
+                ntiles -= 2 * U;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], nxt[u][j], ldsY, lane32);
+            }
+            if (ntiles >= U) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1251,8 +1283,26 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
             for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
             soff += U * kTileBytes;
             ntiles -= U;
-            while (ntiles >= U) {
-                u32x4 nxt[U];
+            // as in the tile kernel: two register sets in turn, one batch in flight
+            u32x4 nxt[U];
+            while (ntiles >= 2 * U) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
+#pragma unroll
+                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + (U + u) * kTileBytes);
+                __builtin_amdgcn_sched_barrier(0);
+                soff += 2 * U * kTileBytes;
+                ntiles -= 2 * U;
+#pragma unroll
+                for (int u = 0; u < U; ++u) horner_step(acc, nxt[u], ldsY, lane32);
+            }
+            if (ntiles >= U) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
                 soff += U * kTileBytes;
