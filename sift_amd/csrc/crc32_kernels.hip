@@ -123,6 +123,13 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);  // which table copy this lane reads
     const uint32_t row32 = tid & 31u;                     // its row in a 32-lane product
     const int64_t g = blockIdx.x;
+#if defined(SIFT_TRACE_FINISH)  // timing-only build (tools/trace_groups.py): 100 MHz clock at four points per group
+#define SIFT_TRACE(slot) \
+    if (tid == 0 && a.single_launch) a.partial[(slot) * 256 + g] = (uint32_t)wall_clock64()
+#else
+#define SIFT_TRACE(slot)
+#endif
+    SIFT_TRACE(0);
 
     // This workgroup's virtual tiles [tv0, tv1); the ones before pad_tiles are
     // all-zero padding in front of the message and contribute nothing.
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));  // pin: do not sink past the loop
     __syncthreads();
+    SIFT_TRACE(1);
 
     if (USE_Y) {
         if (batched) {
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         }
     }
 
+    SIFT_TRACE(2);
     // Lane residue: each of its vectors folded over its four words with the
     // x^32 table, earlier vectors carried forward by x^(128*kThreads) (uniform
     // constant, rows C1); then the lane's place in the tile; then XOR over the
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         return;
     }
 
+    SIFT_TRACE(3);
     // Weight: x * z^h, h = G-1-g, as a product of the z^(2^s) with bit s of h
     // set; each factor applied by the half-wave together (lane k holds row k).
     const uint32_t G = (uint32_t)f.groups;

@@ -56,6 +56,28 @@ __global__ __launch_bounds__(1024) void read_runs(const u32x4* base, size_t tile
     if (r == 0x12345678u) out[blockIdx.x] = r;  // keeps the loads alive
 }
 
+// read_runs, but the groups with (blockIdx & mask) != 0 walk their run from its
+// last tile down: does the direction of a stream matter to the memory system?
+template <int U>
+__global__ __launch_bounds__(1024) void read_runs_updown(const u32x4* base, size_t tiles_per_group,
+                                                         uint32_t mask, uint32_t* out) {
+    const bool down = (blockIdx.x & mask) != 0;
+    const u32x4* p = base + (size_t)blockIdx.x * tiles_per_group * 1024 + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t t = 0; t + U <= tiles_per_group; t += U) {
+        u32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t tt = down ? tiles_per_group - 1 - (t + u) : t + u;
+            w[u] = __builtin_nontemporal_load(p + tt * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= w[u];
+    }
+    uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[blockIdx.x] = r;
+}
+
 // read_runs<2> plus synthetic work per loaded vector: V rounds of 4 VALU ops per
 // word and L conflict-free LDS lookups per word (same table layout as the CRC
 // kernel).  Separates "the loop has arithmetic" from "the loop reads LDS".
@@ -285,6 +307,29 @@ int main(int argc, char** argv) {
             std::printf("stream spacing: runs of %zu tiles  median %7.2f us  %7.1f GB/s\n", tp[v],
                         tt[5] * 1e3, bytes / (tt[5] * 1e-3) / 1e9);
         }
+    }
+    // Direction of the streams: all up, odd groups down, all down.
+    {
+        const uint32_t masks[3] = {0u, 1u, 0xFFFFFFFFu};
+        const char* dn[3] = {"all groups walk up", "odd groups walk down", "all groups walk down"};
+        for (int rep = 0; rep < 2; ++rep)
+            for (int v = 0; v < 3; ++v) {
+                std::vector<float> tt;
+                for (int r = 0; r < 12; ++r) {
+                    float t;
+                    CK(hipEventRecord(e0));
+                    if (masks[v] == 0xFFFFFFFFu)
+                        read_runs_updown<2><<<256, 1024>>>((const u32x4*)buf + 0, tpg, 0x1FFu, out);  // every group: (g & 0x1ff) != 0 except g = 0
+                    else
+                        read_runs_updown<2><<<256, 1024>>>((const u32x4*)buf, tpg, masks[v], out);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&t, e0, e1));
+                    if (r >= 2) tt.push_back(t);
+                }
+                std::sort(tt.begin(), tt.end());
+                std::printf("direction: %-24s median %7.2f us  min %7.2f us\n", dn[v], tt[5] * 1e3, tt[0] * 1e3);
+            }
     }
     // Where does the CRC loop's ~3 % streaming loss come from?  Pure read with
     // synthetic VALU-only, LDS-only and combined work of the CRC loop's size.
