@@ -73,6 +73,41 @@ __device__ __forceinline__ void horner_step(u32x4& acc, const u32x4 w, const uin
         acc[c] = (c < SIFT_ABLATE_WORDS ? mul_y(acc[c], ldsY, lane32) : acc[c]) ^ w[c];
 }
 
+// A 1024-entry table into LDS with every entry copied kRepl times in a row
+// (mul_y's layout), from four entries per lane in registers: lane t holds
+// entries 4(t>>2) .. +3 (ONE 16-byte load, `stage_fetch`) and writes the quarter
+// (t & 3) of the copies of each with 16-byte stores.  A word-by-word fill takes a
+// lane 32 loads, each 16 cycles of the CU's address unit.
+__device__ __forceinline__ u32x4 stage_fetch(const uint32_t* table, uint32_t q) {
+    return reinterpret_cast<const u32x4*>(table)[q >> 2];
+}
+__device__ __forceinline__ void stage_store(uint32_t* ldsT, const u32x4 e, uint32_t q) {
+    constexpr int kQuarter = kRepl / 4;  // copies of an entry one lane writes
+    static_assert(kQuarter % 4 == 0 || kQuarter == 2, "SIFT_REPL");
+    const uint32_t quad = q >> 2, part = q & 3u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t* dst = ldsT + (quad * 4u + (uint32_t)w) * (uint32_t)kRepl + part * (uint32_t)kQuarter;
+        if constexpr (kQuarter % 4 == 0) {
+            const u32x4 v = {e[w], e[w], e[w], e[w]};
+#pragma unroll
+            for (int r = 0; r < kQuarter / 4; ++r) reinterpret_cast<u32x4*>(dst)[r] = v;
+        } else {
+            dst[0] = e[w];
+            dst[1] = e[w];
+        }
+    }
+}
+
+// A value every lane of the wave agrees on, moved to scalar registers (the
+// compiler sometimes computes uniform 64-bit selects on the vector unit, and a
+// buffer descriptor built from vector registers costs a loop per load).
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u32x4 load_vec(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
 // One lane's vector of a whole tile: buffer_load_dwordx4, non-temporal (the
@@ -114,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // One array (see the guide's second-__shared__-object trap); the one-tile
     // variant needs no y table and so leaves the CU's LDS to other workgroups.
     constexpr int kYUsed = USE_Y ? kYWords : 0;
-    __shared__ uint32_t lds[kYUsed + kXWords + kWaves];
+    __shared__ __align__(16) uint32_t lds[kYUsed + kXWords + kWaves];
     uint32_t* ldsY = lds;
     uint32_t* ldsX = lds + kYUsed;
     uint32_t* red = ldsX + kXWords;
@@ -138,42 +173,56 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     if (tv0 < a.pad_tiles) tv0 = a.pad_tiles;
     int64_t ntiles = tv1 - tv0;
 
+    // Straight-line prologue, so that the compiler can count the loads in flight:
+    // the table words this lane will put into LDS are asked for FIRST (three
+    // 16-byte / 4-byte loads, L2 hits), the message right behind them.  Loads
+    // return in order, so the tables are staged and the lane's matrix rows built
+    // while the first message bytes are still on their way from HBM; asked for
+    // after the message, they used to arrive behind it.
+    constexpr int kStageRounds = USE_Y ? (1024 + kThreads - 1) / kThreads : 0;  // 1 at 1024 lanes
+    constexpr int kXRounds = (kXWords + kThreads - 1) / kThreads;
+    u32x4 ty[kStageRounds > 0 ? kStageRounds : 1];
+    uint32_t tx[kXRounds];
+#if !defined(SIFT_ABLATE_FILL)
+#pragma unroll
+    for (int k = 0; k < kStageRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads);
+        ty[k] = stage_fetch(a.tabs->Y, q < 1024u ? q : 0u);
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < kXRounds; ++k) {
+        const uint32_t i = tid + (uint32_t)(k * kThreads);
+        tx[k] = a.tabs->X[i < (uint32_t)kXWords ? i : 0u];
+    }
+    uint32_t kb[32];
+    kb[0] = a.tabs->Kt[tid];
+    __builtin_amdgcn_sched_barrier(0);
+
     // A lane holds kVpl vectors of a tile (vector t + j*kThreads for j < kVpl),
     // each with its own four running words: kVpl independent Horner chains.
+    // Tiles are aligned to the END of the body, so only the first real tile can
+    // start before vector 0: lanes in front of it (and every lane of a group
+    // without tiles) ask at an offset the descriptor does not cover and get zeros
+    // without a memory access.  The head of the message is fixed up after staging.
+    constexpr int kBeyond = 0x7FFFFFF0;
+    const bool has = ntiles > 0;
+    const int64_t v0 = (int64_t)uniform64((uint64_t)(has ? a.nvec - (a.virtual_tiles - tv0) * (int64_t)kTileVecs : 0));
     u32x4 acc[kVpl];
-#pragma unroll
-    for (int j = 0; j < kVpl; ++j) acc[j] = u32x4{0u, 0u, 0u, 0u};
-    // `p` is the tile's first vector: the same for every lane, so it and its
-    // increments live in scalar registers and each load is base + lane offset.
-    const u32x4* p = a.vbase;
-    if (ntiles > 0) {
-        // Tiles are aligned to the END of the body, so only the first real tile
-        // can start before vector 0.
-        const int64_t v0 = a.nvec - (a.virtual_tiles - tv0) * (int64_t)kTileVecs;
-        p = a.vbase + v0;
+    {
+        const __amdgpu_buffer_rsrc_t srd0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u32x4*>(a.vbase + v0), /*stride*/ 0, kTileBytes, 0x00020000);
 #pragma unroll
         for (int j = 0; j < kVpl; ++j) {
             const int64_t vi = v0 + (int64_t)(j * kThreads) + (int64_t)tid;
-            if (vi >= 0) {
-                acc[j] = load_vec(p + j * kThreads + tid);
-                if (vi == 0) {
-                    if (a.head_skip) acc[j] = mask_head(acc[j], a.head_skip);
-                    acc[j][0] ^= a.state_ptr ? gf2_mulmod(*a.state_ptr, a.xinv_h) : a.state_fold;
-                }
-            }
+            acc[j] = load_tile(srd0, has && vi >= 0 ? (int)((j * kThreads + tid) * 16u) : kBeyond, 0);
         }
-        p += kTileVecs;
-        --ntiles;
     }
-
-    // Single-launch finish (a.single_launch): wave 0 will weight this group's
-    // residue by z^(G-1-g) at the end; fetch its matrix rows now, behind the
-    // first data load.
-    uint32_t rows[kTreeLevels];
-    if (a.single_launch && tid < 64u) {
-#pragma unroll
-        for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][row32];
-    }
+    // `p` is the next tile's first vector: the same for every lane, so it and its
+    // increments live in scalar registers and each load is base + lane offset.
+    const u32x4* p = reinterpret_cast<const u32x4*>(
+        uniform64(reinterpret_cast<uint64_t>(a.vbase + v0 + (has ? kTileVecs : 0))));
+    ntiles = (int64_t)uniform64((uint64_t)(has ? ntiles - 1 : ntiles));
 
     // The rest of the run goes through a buffer descriptor: 128-bit SRD in
     // scalar registers, per-lane offset tid*16 in one VGPR, tile offset in an
@@ -185,42 +234,63 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     const int voff = (int)(tid * 16u);
     int soff = 0;
     constexpr int U = kUnroll;
-    // First batch of the main loop is issued BEFORE the tables are staged, so
-    // HBM latency and the table fill overlap.
+    // First batch of the main loop, also before the tables are staged.
     u32x4 cur[U][kVpl];
     const bool batched = USE_Y && ntiles >= U;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < kVpl; ++j)
+            cur[u][j] = load_tile(srd, batched ? voff : kBeyond, soff + u * kTileBytes + j * kThreads * 16);
     if (batched) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < kVpl; ++j)
-                cur[u][j] = load_tile(srd, voff, soff + u * kTileBytes + j * kThreads * 16);
         soff += U * kTileBytes;
         ntiles -= U;
     }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // Tables: global (L2-resident, 8 KiB) -> LDS.
-#if defined(SIFT_ABLATE_FILL)
-    if (USE_Y && tid == 5000) {
-#else
-    if (USE_Y) {
-#endif
-#pragma unroll 16
-        for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = a.tabs->Y[i >> kReplLog2];
+    // Tables -> LDS.
+#if !defined(SIFT_ABLATE_FILL)
+#pragma unroll
+    for (int k = 0; k < kStageRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads);
+        if (q < 1024u) stage_store(ldsY, ty[k], q);
     }
-    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = a.tabs->X[i];
+#endif
+#pragma unroll
+    for (int k = 0; k < kXRounds; ++k) {
+        const uint32_t i = tid + (uint32_t)(k * kThreads);
+        if (i < (uint32_t)kXWords) ldsX[i] = tx[k];
+    }
     // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its
     // multiplication matrix: computed here, while the first loads are in flight
     // and the VALU is idle, and kept in registers through the main loop, so that
     // the multiply at the end is 3 instructions per bit instead of 7.
-    uint32_t kb[32];
-    kb[0] = a.tabs->Kt[tid];
 #pragma unroll
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));  // pin: do not sink past the loop
     __syncthreads();
     SIFT_TRACE(1);
+
+    // The head of the message: the lane that holds vector 0 zeroes the bytes in
+    // front of it and folds the starting register in.
+    if (has) {
+#pragma unroll
+        for (int j = 0; j < kVpl; ++j) {
+            const int64_t vi = v0 + (int64_t)(j * kThreads) + (int64_t)tid;
+            if (vi == 0) {
+                if (a.head_skip) acc[j] = mask_head(acc[j], a.head_skip);
+                acc[j][0] ^= a.state_ptr ? gf2_mulmod(*a.state_ptr, a.xinv_h) : a.state_fold;
+            }
+        }
+    }
+    // Single-launch finish (a.single_launch): wave 0 will weight this group's
+    // residue by z^(G-1-g) at the end; its matrix rows have the whole stream to arrive.
+    uint32_t rows[kTreeLevels];
+    if (a.single_launch && tid < 64u) {
+#pragma unroll
+        for (int s = 0; s < kTreeLevels; ++s) rows[s] = m.z[s][row32];
+    }
 
     if (USE_Y) {
         if (batched) {

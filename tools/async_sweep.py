@@ -10,7 +10,7 @@ pool = torch.randint(0, 256, (2 << 30,), dtype=torch.uint8, device="cuda")
 ws = torch.zeros(sift_amd.workspace_bytes(), dtype=torch.uint8, device="cuda")
 out = torch.zeros(1, dtype=torch.int32, device="cuda")
 rows = {}
-for size in (1 << 20, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30):
+for size in (1 << 20, 2 << 20, 4 << 20, 8 << 20, 12 << 20, 16 << 20, 24 << 20, 32 << 20, 64 << 20, 128 << 20, 256 << 20, 1 << 30):
     ns = max(2, min(pool.numel() // size, max(8, (512 << 20) // size)))
     stride = (pool.numel() // ns) // 4096 * 4096
     sl = [pool[k * stride:k * stride + size] for k in range(ns)]
