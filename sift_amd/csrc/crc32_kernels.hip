@@ -1223,6 +1223,22 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
 
     const CutArgs& c = b.cut;
     const uint32_t tid = threadIdx.x;
+    // The table words this lane will put into LDS are asked for first (four
+    // loads), so that they travel while the piece list / the items' descriptors
+    // and headers are read.
+    static_assert(kXWords == 1024 && kZWords == 1024, "tables of 1024 words");
+    constexpr int kRounds = (1024 + kThreads - 1) / kThreads;  // 1 at 1024 lanes
+    u32x4 ty[kRounds];
+    uint32_t tx[kRounds], tz[kRounds];
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads) < 1024u ? tid + (uint32_t)(k * kThreads) : 0u;
+        ty[k] = stage_fetch(b.tabs->Y, q);
+        tx[k] = b.tabs->X[q];
+        tz[k] = (&b.tabs->X2[0][0])[q];
+    }
+    uint32_t kb[32];
+    kb[0] = b.tabs->Kt[tid];
     uint32_t total;
     if (PLAN) {
         total = plan_items(b, prec, plan_pbase, plan_pbase + kPlanMax);
@@ -1240,12 +1256,15 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
 
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
     const uint32_t row32 = tid & 31u;
-#pragma unroll 16
-    for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y[i >> kReplLog2];
-    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
-    for (int i = tid; i < kZWords; i += kThreads) ldsZ[i] = (&b.tabs->X2[0][0])[i];
-    uint32_t kb[32];
-    kb[0] = b.tabs->Kt[tid];
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads);
+        if (q < 1024u) {
+            stage_store(ldsY, ty[k], q);
+            ldsX[q] = tx[k];
+            ldsZ[q] = tz[k];
+        }
+    }
 #pragma unroll
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
 #pragma unroll
