@@ -75,6 +75,16 @@ traffic = {
 with open(os.path.join(PR, "traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 
+# per-launch durations of the tile kernel from the same trace: the --stats average
+# takes in the rare launch that is descheduled for milliseconds, the median does not
+durs = []
+with open(one(f"{rnd}_trace/*/*kernel_trace.csv")) as f:
+    for r in csv.DictReader(f):
+        if KERNEL in r["Kernel_Name"] and "true" in r["Kernel_Name"]:
+            durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+durs.sort()
+trimmed = durs[: max(1, len(durs) * 99 // 100)]  # without the slowest 1 %
+
 vec = alg / 1024.0  # wave-level 1 KiB loads per launch
 summary = {
     "round": rnd,
@@ -84,6 +94,10 @@ summary = {
         "avg_us": float(stats["AverageNs"]) / 1e3, "min_us": float(stats["MinNs"]) / 1e3,
         "max_us": float(stats["MaxNs"]) / 1e3,
         "GBps_at_avg": alg / float(stats["AverageNs"]),
+        "median_us": durs[len(durs) // 2] if durs else None,
+        "p90_us": durs[len(durs) * 9 // 10] if durs else None,
+        "avg_us_without_slowest_1pct": sum(trimmed) / len(trimmed) if durs else None,
+        "launches_over_1ms": sum(1 for d in durs if d > 1000.0),
     },
     "pmc_per_launch": pmc,
     "derived": {
@@ -102,3 +116,22 @@ with open(os.path.join(PR, f"{rnd}_summary.json"), "w") as f:
 print(json.dumps(summary["rocprof_kernel_trace"], indent=1))
 print(json.dumps(summary["derived"], indent=1))
 print(json.dumps(traffic, indent=1))
+
+# the other files tools/collect_profiles.sh leaves under gpurun_out/
+import shutil
+
+for src, dst in ((f"bench_{rnd}.json", f"{rnd}_bench.json"), (f"{rnd}_batch_bench.json", f"{rnd}_batch_bench.json"),
+                 (f"{rnd}_size_sweep.json", f"{rnd}_size_sweep.json"), (f"{rnd}_async_sweep.json", f"{rnd}_async_sweep.json"),
+                 (f"{rnd}_group_trace.txt", f"{rnd}_group_trace.txt")):
+    if os.path.exists(os.path.join(GO, src)):
+        shutil.copyfile(os.path.join(GO, src), os.path.join(PR, dst))
+hits = glob.glob(os.path.join(GO, f"{rnd}_batch_trace/*/*kernel_stats.csv"))
+if hits:
+    with open(max(hits, key=os.path.getmtime)) as f:
+        brows = list(csv.DictReader(f))
+    with open(os.path.join(PR, f"{rnd}_batch_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=brows[0].keys())
+        w.writeheader()
+        for r in brows:
+            r["Name"] = r["Name"][:120]
+            w.writerow(r)
