@@ -120,6 +120,9 @@ def main() -> None:
     ap.add_argument("--event-stride", type=int, default=0,
                     help="bracket every n-th launch's tile kernel with HIP events; 0 = every launch "
                          "when steps < 64, else about 64 samples")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="with one GPU: still open the RCCL process group (one rank) and run every "
+                         "collective of the N > 1 leg, so that those lines have run on hardware")
     ap.add_argument("--dry-collective", action="store_true",
                     help="run only the N > 1 exchange, on CPU tensors over gloo (no GPU)")
     args = ap.parse_args()
@@ -138,7 +141,13 @@ def main() -> None:
                          f"torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.rehearse_collective
+    if collective:
+        if world == 1:  # rehearsal without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import sift_amd
@@ -168,14 +177,14 @@ def main() -> None:
         every pass is stitched."""
         for i in range(steps):
             sharded.local_state_async(0xFFFFFFFF, bufs[i % R], rank, pairs[i], ws)
-        if world > 1:
+        if collective:
             return sharded.exchange_and_stitch(pairs[:steps])
         torch.cuda.synchronize()
         return [int(s) & 0xFFFFFFFF for s in pairs[:steps, 0].cpu().tolist()]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -203,7 +212,7 @@ def main() -> None:
     samples = (C.c_float * max(K, 1))()
     _lib.check(_lib.lib.sift_profile_end_samples(local_rank, C.byref(kms), C.byref(kl), samples, K))
 
-    if world > 1:
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -240,7 +249,7 @@ def main() -> None:
                 "preheat_ms": args.preheat_ms,
                 "result": f"0x{results[0]:08x}",
                 "parallelism": f"range-sharded x{world}, one (state,len) all-gather per job" if world > 1
-                               else "single GPU",
+                               else ("single GPU (one-rank RCCL group rehearsed)" if collective else "single GPU"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -266,7 +275,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
