@@ -995,12 +995,21 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // extent / wave_max records, and a record of body B has at most B / piece + 1
     // pieces.  Items that overlap can exceed this; a span that finds the arrays
     // full is walked by its own wave instead (same bits, slower).
-    const bool cut = g_batch_cut.load() != 0;
+    bool cut = g_batch_cut.load() != 0;
     const int tuned_wave_max = g_batch_wave_max.load(), piece_log2 = g_batch_piece_log2.load();
     const uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max
                                                  : (n >= 4096u ? (256u << 10) : (32u << 10));
+    // Lengths the host can read (host or pinned arrays), not too many of them: if no
+    // item can hold a span longer than wave_max, nothing will be filed and the call is
+    // the wave kernel alone -- no scratch, no second launch (6 us of an otherwise 8 us call).
+    const bool host_lens = w_len != Where::Device;
+    if (cut && host_lens && n > kPlanMax && n <= 4096u) {
+        uint64_t longest = 0;
+        for (uint32_t i = 0; i < n; ++i) longest = std::max(longest, lens[i]);
+        if (longest <= wave_max) cut = false;  // a span is never longer than its item
+    }
     uint64_t extent = 1ull << 30;
-    {
+    if (cut) {
         hipDeviceptr_t abase = nullptr;
         size_t asize = 0;
         if (hipMemGetAddressRange(&abase, &asize, const_cast<void*>(d_base)) == hipSuccess && asize) {
@@ -1054,7 +1063,18 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         b.cut.wave_max = wave_max;
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     }
-    const size_t copy_bytes = (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
+    // Few items with descriptors the host can read: they go into the kernel arguments.
+    InlineDesc inl;
+    const bool use_inline = plan && host_lens && w_off != Where::Device;
+    if (use_inline) {
+        for (uint32_t i = 0; i < n; ++i) {
+            inl.v[2 * i] = offsets[i];
+            inl.v[2 * i + 1] = lens[i];
+        }
+        for (uint32_t i = 2 * n; i < 2 * kPlanMax; ++i) inl.v[i] = 0;
+    }
+    const size_t copy_bytes =
+        use_inline ? 0 : (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
     uint8_t* d_desc = nullptr;   // stream-ordered allocation (large descriptor arrays)
     int stage_buf = -1;          // or one of the stream's two pinned buffers (small ones)
     if (copy_bytes && copy_bytes <= kDescStageBytes) {
@@ -1110,13 +1130,13 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     const int groups = (int)std::min<uint64_t>((wave_chunks + waves_per_group - 1) / waves_per_group,
                                                (uint64_t)c->groups_max);
     if (plan) {
-        launch_pieces(b, c->groups_max, true, st);
+        launch_pieces(b, c->groups_max, true, use_inline ? &inl : nullptr, st);
         SIFT_HIP(hipGetLastError());
     } else {
         launch_batch(b, groups, st);
         SIFT_HIP(hipGetLastError());
         if (cut) {
-            launch_pieces(b, c->groups_max, false, st);
+            launch_pieces(b, c->groups_max, false, nullptr, st);
             SIFT_HIP(hipGetLastError());
         }
     }

@@ -177,8 +177,16 @@ struct BatchArgs {
     CutArgs cut;
 };
 
+// Up to kPlanMax items whose descriptors the host can read travel in the kernel
+// arguments themselves (offset, length pairs): no staging copy and no PCIe read.
+// A second argument of the planned piece kernel only, so that no other launch
+// carries the kilobyte.
+struct InlineDesc {
+    uint64_t v[2 * kPlanMax];
+};
+
 void launch_batch(const BatchArgs& b, int groups, void* stream);
-void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream);
+void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream);
 void launch_clear(uint32_t* words, int n, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream);

@@ -21,6 +21,8 @@
 //     of the two-launch A/B form (tree over the <= 1024 residues).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "crc32_device.h"
 #include "gf2.h"
 
@@ -1108,15 +1110,16 @@ __device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecor
 // piece bases.  The plan lands in LDS as CutRecords.  Items that end without a
 // span to stream (an error before the CRC, or a span under 32 bytes, walked by
 // the lane) get their verdict from workgroup 0 alone.  Returns the piece total.
-__device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, CutRecord* prec, uint32_t* pbase_lds,
-                                               uint32_t* total_lds) {
+__device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, const uint64_t* inl, CutRecord* prec,
+                                               uint32_t* pbase_lds, uint32_t* total_lds) {
     const uint32_t tid = threadIdx.x;
     if (tid < 64u) {
         const uint32_t i = tid;
         uint32_t np = 0, level = 0, dlen = 0;
         uint64_t span_off = 0, span_len = 0;
         if (i < b.n) {
-            const uint64_t off = b.offsets[i], avail = b.lens[i];
+            const uint64_t off = inl ? inl[2u * i] : b.offsets[i];
+            const uint64_t avail = inl ? inl[2u * i + 1u] : b.lens[i];
             const uint8_t* ptr = b.base + off;
             uint32_t status = 0;
             bool pending = true;
@@ -1209,8 +1212,13 @@ __device__ __forceinline__ void leave_pieces(const CutArgs& c, uint32_t groups) 
 // PLAN = true:  few items; every workgroup plans them itself (plan_items), the
 //               records are in LDS and only their accumulators (c.recs[i].acc /
 //               .arrived, zero between calls) in device memory.
-template <bool PLAN>
-__global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
+//               INL: their descriptors are in the second argument instead of b.offsets / b.lens.
+struct NoInline {
+    uint32_t unused;
+};
+template <bool PLAN, bool INL>
+__global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
+                                                                std::conditional_t<INL, InlineDesc, NoInline> d) {
     constexpr int kZWords = 32 * 32;
     constexpr int kPlanWords = PLAN ? (int)(kPlanMax * sizeof(CutRecord) / 4 + kPlanMax + 16) : 0;
     __shared__ __align__(16) uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves + kPlanWords];
@@ -1241,7 +1249,9 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b) {
     kb[0] = b.tabs->Kt[tid];
     uint32_t total;
     if (PLAN) {
-        total = plan_items(b, prec, plan_pbase, plan_pbase + kPlanMax);
+        const uint64_t* inl = nullptr;
+        if constexpr (INL) inl = d.v;
+        total = plan_items(b, inl, prec, plan_pbase, plan_pbase + kPlanMax);
     } else {
         const unsigned long long reserved = *c.pieces;
         total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
@@ -1484,13 +1494,14 @@ void launch_batch(const BatchArgs& b, int groups, void* stream) {
     }
 }
 
-void launch_pieces(const BatchArgs& b, int groups, bool plan, void* stream) {
-    if (plan)
-        hipLaunchKernelGGL(crc32_pieces_kernel<true>, dim3(groups), dim3(kThreads), 0,
-                           static_cast<hipStream_t>(stream), b);
+void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan && inl)
+        hipLaunchKernelGGL((crc32_pieces_kernel<true, true>), dim3(groups), dim3(kThreads), 0, s, b, *inl);
+    else if (plan)
+        hipLaunchKernelGGL((crc32_pieces_kernel<true, false>), dim3(groups), dim3(kThreads), 0, s, b, NoInline{0u});
     else
-        hipLaunchKernelGGL(crc32_pieces_kernel<false>, dim3(groups), dim3(kThreads), 0,
-                           static_cast<hipStream_t>(stream), b);
+        hipLaunchKernelGGL((crc32_pieces_kernel<false, false>), dim3(groups), dim3(kThreads), 0, s, b, NoInline{0u});
 }
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,

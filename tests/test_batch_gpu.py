@@ -286,3 +286,61 @@ def test_batch_argument_errors_and_edges(gpu, oracle):
     for k, o in enumerate(outs):
         assert [int(v) & 0xFFFFFFFF for v in o.cpu().tolist()] == \
             [oracle.compute(0xFFFFFFFF, h[k:k + 1000 + k]), oracle.compute(0xFFFFFFFF, h[k + 1:k + 1 + 7 * k])]
+
+
+def test_descriptor_locations_and_batch_sizes(gpu, oracle):
+    # The same items with descriptors in pageable host memory, in pinned host memory
+    # and in HBM, for batch sizes on both sides of every path switch: up to 64 items
+    # the host's descriptors travel in the kernel arguments; up to 4096 the host looks
+    # at the lengths and, if none can be long, launches the wave kernel alone; with a
+    # long item among them the piece kernel follows.  Same bits on every path.
+    rng = np.random.default_rng(77)
+    blob = rng.integers(0, 256, size=12 << 20, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    for n, with_long in ((1, False), (1, True), (7, True), (64, False), (64, True), (65, False), (65, True),
+                         (300, False), (300, True), (4096, False), (4097, False)):
+        lens = [int(x) for x in rng.integers(0, 6000, size=n)]
+        if with_long:
+            lens[n // 2] = (2 << 20) + 11
+        offs, pos = [], 0
+        for ln in lens:
+            pos += int(rng.integers(0, 23))
+            if pos + ln > blob.size:
+                pos = int(rng.integers(0, 64))
+            offs.append(pos)
+            pos += ln
+        want = np.array([oracle.compute(0x2468ACE0, blob[o:o + ln]) for o, ln in zip(offs, lens)], dtype=np.uint32)
+        pin_o = torch.tensor(offs, dtype=torch.int64).pin_memory()
+        pin_l = torch.tensor(lens, dtype=torch.int64).pin_memory()
+        variants = {
+            "pageable": (offs, lens),
+            "pinned": (pin_o.numpy().view(np.uint64), pin_l.numpy().view(np.uint64)),
+            "device": (torch.tensor(offs, dtype=torch.int64, device="cuda"),
+                       torch.tensor(lens, dtype=torch.int64, device="cuda")),
+        }
+        for name, (o, ln) in variants.items():
+            for rep in range(2):  # twice in a row: staging buffers and scratch are reused
+                got = gpu.compute_batch(0x2468ACE0, d, o, ln).cpu().numpy().view(np.uint32)
+                assert (got == want).all(), (n, with_long, name, rep, np.nonzero(got != want)[0][:5])
+
+
+def test_small_chunk_batches_from_host_descriptors(gpu, oracle):
+    # Chunk::read and Chunk::write's crc step on a handful of chunks described from the host
+    # (kernel-argument descriptors), including a corrupted one and a truncated one.
+    from sift_amd import container
+    rng = np.random.default_rng(78)
+    stream = bytearray()
+    offs, avail, want = [], [], []
+    for i, n in enumerate([0, 5, 100, 4096, 70000, 1 << 20, 33]):
+        data = rng.integers(0, 256, size=n, dtype=np.uint8)
+        ser = bytearray(oracle.write_chunk(b"AMRG", data))
+        if i == 2:
+            ser[10] ^= 1
+        offs.append(len(stream))
+        avail.append(len(ser) - (3 if i == 4 else 0))
+        st, _, _, dl, _ = oracle.read_chunk(bytes(ser[:avail[-1]]))
+        want.append((st, dl if st == 0 else 0))
+        stream += ser
+    d = torch.from_numpy(np.frombuffer(bytes(stream), dtype=np.uint8).copy()).cuda()
+    status, dlen = container.read_chunks_device(d, offs, avail)
+    assert list(zip(status.cpu().tolist(), dlen.cpu().tolist())) == want

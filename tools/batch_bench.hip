@@ -103,6 +103,41 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    // Small batches: n buffers of 4 KiB (what a call costs when there is little to do)
+    for (uint32_t n : {1u, 16u, 64u, 256u, 4096u}) {
+        if (only_chunk) break;
+        const size_t size = 4096;
+        for (uint32_t i = 0; i < n; ++i) {
+            off[i] = (uint64_t)i * size;
+            len[i] = size;
+        }
+        CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
+        for (int where = 0; where < 2; ++where) {
+            const uint64_t* po = where ? off.data() : d_off;
+            const uint64_t* pl = where ? len.data() : d_len;
+            for (int i = 0; i < 3; ++i)
+                SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, po, pl, n, d_out, s));
+            CK(hipStreamSynchronize(s));
+            const int reps = 200;
+            CK(hipEventRecord(e0, s));
+            const double t0 = now();
+            for (int i = 0; i < reps; ++i)
+                SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, po, pl, n, d_out, s));
+            const double t_issue = now() - t0;
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            const double t_wall = now() - t0;
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%s {\"kind\": \"small_batch\", \"descriptors\": \"%s\", \"buffer_bytes\": %zu, \"buffers\": %u, "
+                   "\"issue_us_per_call\": %.2f, \"wall_us_per_call\": %.2f, \"device_us_per_call\": %.2f}",
+                   first ? "" : ",\n", where ? "host" : "device", size, n, t_issue / reps * 1e6, t_wall / reps * 1e6,
+                   ms * 1e3 / reps);
+            first = false;
+            fflush(stdout);
+        }
+    }
     // Chunk::read on ONE serialized chunk: length only in its header
     for (size_t n : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20, ((size_t)1 << 30) - 16}) {
         if (only_chunk && n != only_n) continue;
