@@ -164,13 +164,23 @@ struct StreamScratch {
     // CPU into one of two pinned buffers which the kernels read in place (no copy
     // command: hipMemcpyAsync from pageable memory costs 100-300 us of fixed time
     // at these sizes).  A buffer is reused once the call that read it has finished.
-    uint8_t* h_desc = nullptr;       // 2 * kDescStageBytes, pinned
+    // Arrays of up to kDescSmallBytes (4096 items) go through a ring of 16 small
+    // buffers in two halves with ONE event per half, recorded behind the call that
+    // uses a half's last buffer and waited for before its first buffer is used again:
+    // an event record costs the stream about 3 us, a third of a small batch call.
+    uint8_t* h_desc = nullptr;       // 2 * kDescStageBytes + kDescSmallSlots * kDescSmallBytes, pinned
     uint8_t* d_desc = nullptr;       // the same memory as the device addresses it
     hipEvent_t desc_read[2] = {nullptr, nullptr};
     bool desc_used[2] = {false, false};
     unsigned desc_next = 0;
+    hipEvent_t half_read[2] = {nullptr, nullptr};
+    bool half_begun[2] = {false, false};   // a buffer of this half has been handed out since its last wait
+    bool half_closed[2] = {false, false};  // ... and the event behind its last buffer has been recorded
+    unsigned small_next = 0;
 };
 constexpr size_t kDescStageBytes = 1u << 20;
+constexpr size_t kDescSmallBytes = 64u << 10;
+constexpr unsigned kDescSmallSlots = 16;
 
 struct DeviceCtx {
     int device = -1;
@@ -226,6 +236,8 @@ void destroy_ctx(DeviceCtx* c) {  // the device is current
         (void)hipFree(kv.second.batch);
         if (kv.second.h_desc) (void)hipHostFree(kv.second.h_desc);
         for (hipEvent_t e : kv.second.desc_read)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : kv.second.half_read)
             if (e) (void)hipEventDestroy(e);
     }
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -1076,21 +1088,41 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     const size_t copy_bytes =
         use_inline ? 0 : (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
     uint8_t* d_desc = nullptr;   // stream-ordered allocation (large descriptor arrays)
-    int stage_buf = -1;          // or one of the stream's two pinned buffers (small ones)
+    int stage_buf = -1;          // or one of the stream's two pinned buffers (up to 1 MiB)
+    int small_slot = -1;         // or one of its ring of small ones
     if (copy_bytes && copy_bytes <= kDescStageBytes) {
         StreamScratch& ss = c->per_stream[st];
         if (!ss.h_desc) {
             uint8_t* h = nullptr;
-            SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), 2 * kDescStageBytes, hipHostMallocDefault));
+            SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h),
+                                   2 * kDescStageBytes + kDescSmallSlots * kDescSmallBytes, hipHostMallocDefault));
             ss.h_desc = h;
             SIFT_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ss.d_desc), h, 0));
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
                 SIFT_HIP(hipEventCreateWithFlags(&ss.desc_read[i], hipEventDisableTiming));
+                SIFT_HIP(hipEventCreateWithFlags(&ss.half_read[i], hipEventDisableTiming));
+            }
         }
-        stage_buf = (int)(ss.desc_next++ & 1u);
-        if (ss.desc_used[stage_buf]) SIFT_HIP(hipEventSynchronize(ss.desc_read[stage_buf]));
-        uint8_t* hp = ss.h_desc + (size_t)stage_buf * kDescStageBytes;
-        const uint8_t* dp = ss.d_desc + (size_t)stage_buf * kDescStageBytes;
+        size_t at;  // where the buffer starts in h_desc / d_desc
+        if (copy_bytes <= kDescSmallBytes) {
+            small_slot = (int)(ss.small_next++ % kDescSmallSlots);
+            const int half = small_slot / (int)(kDescSmallSlots / 2);
+            if (small_slot % (int)(kDescSmallSlots / 2) == 0) {  // entering a half: its last round must have been read
+                if (ss.half_begun[half]) {
+                    if (ss.half_closed[half]) SIFT_HIP(hipEventSynchronize(ss.half_read[half]));
+                    else SIFT_HIP(hipStreamSynchronize(st));  // a call of that round failed before its record
+                }
+                ss.half_begun[half] = true;
+                ss.half_closed[half] = false;
+            }
+            at = 2 * kDescStageBytes + (size_t)small_slot * kDescSmallBytes;
+        } else {
+            stage_buf = (int)(ss.desc_next++ & 1u);
+            if (ss.desc_used[stage_buf]) SIFT_HIP(hipEventSynchronize(ss.desc_read[stage_buf]));
+            at = (size_t)stage_buf * kDescStageBytes;
+        }
+        uint8_t* hp = ss.h_desc + at;
+        const uint8_t* dp = ss.d_desc + at;
         if (w_off == Where::Host) {
             std::memcpy(hp, offsets, 8ull * n);
             dv_off = dp;
@@ -1145,6 +1177,12 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         StreamScratch& ss = c->per_stream[st];
         SIFT_HIP(hipEventRecord(ss.desc_read[stage_buf], st));
         ss.desc_used[stage_buf] = true;
+    }
+    if (small_slot >= 0 && small_slot % (int)(kDescSmallSlots / 2) == (int)(kDescSmallSlots / 2) - 1) {
+        StreamScratch& ss = c->per_stream[st];
+        const int half = small_slot / (int)(kDescSmallSlots / 2);
+        SIFT_HIP(hipEventRecord(ss.half_read[half], st));
+        ss.half_closed[half] = true;
     }
     return SIFT_OK;
 }

@@ -344,3 +344,26 @@ def test_small_chunk_batches_from_host_descriptors(gpu, oracle):
     d = torch.from_numpy(np.frombuffer(bytes(stream), dtype=np.uint8).copy()).cuda()
     status, dlen = container.read_chunks_device(d, offs, avail)
     assert list(zip(status.cpu().tolist(), dlen.cpu().tolist())) == want
+
+
+def test_many_small_host_descriptor_calls_in_a_row(gpu, oracle):
+    # Pageable descriptors of 65 .. 4096 items go through a ring of 16 small pinned
+    # buffers whose reuse is guarded by one event per half: 50 calls with no host
+    # sync in between, every result checked afterwards.
+    rng = np.random.default_rng(79)
+    blob = rng.integers(0, 256, size=4 << 20, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    calls = []
+    for k in range(50):
+        n = int(rng.integers(65, 400))
+        lens = [int(x) for x in rng.integers(0, 3000, size=n)]
+        offs = [int(x) for x in rng.integers(0, blob.size - 3000, size=n)]
+        calls.append((offs, lens, gpu.compute_batch(0xFFFFFFFF, d, offs, lens)))
+    torch.cuda.synchronize()
+    for k, (offs, lens, out) in enumerate(calls):
+        got = out.cpu().numpy().view(np.uint32)
+        for i in (0, len(offs) // 2, len(offs) - 1):
+            assert int(got[i]) == oracle.compute(0xFFFFFFFF, blob[offs[i]:offs[i] + lens[i]]), (k, i)
+        if k % 7 == 0:
+            want = np.array([oracle.compute(0xFFFFFFFF, blob[o:o + ln]) for o, ln in zip(offs, lens)], dtype=np.uint32)
+            assert (got == want).all(), k
