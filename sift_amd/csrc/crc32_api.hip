@@ -517,10 +517,14 @@ int stream_block_locked(DeviceCtx* c, hipStream_t stream, uint8_t** blk) {
     if (!ss.compute_ws) {
         uint32_t* p = nullptr;
         SIFT_HIP(hipMalloc(&p, kStreamBlockBytes));
-        hipError_t e = hipMemset(p, 0, kStreamBlockBytes);  // synchronous: done before any launch
+        // On the stream itself: its first kernel is ordered behind the clearing.  (A
+        // plain hipMemset runs on the null stream and may still be running when it
+        // returns; a non-blocking stream does not wait for it, and a clearing that
+        // lands in the middle of the first call's exchange breaks every call after it.)
+        hipError_t e = hipMemsetAsync(p, 0, kStreamBlockBytes, stream);
         if (e != hipSuccess) {
             (void)hipFree(p);
-            return fail_hip(e, "hipMemset(workspace)");
+            return fail_hip(e, "hipMemsetAsync(workspace)");
         }
         ss.compute_ws = p;
     }
@@ -620,6 +624,7 @@ int sift_reset_workspace(int device) {
         if (kv.second.batch) SIFT_HIP(hipMemset(kv.second.batch, 0, kCutHeadBytes));
     }
     SIFT_HIP(hipMemset(c->static_scratch, 0, kStaticScratchWords * sizeof(uint32_t)));
+    SIFT_HIP(hipDeviceSynchronize());  // the clearing may outlive hipMemset's return
     return SIFT_OK;
 }
 
