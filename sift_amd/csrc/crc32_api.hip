@@ -55,6 +55,7 @@ constexpr size_t kExchangeWord = kMaxGroups + 32;
 constexpr size_t kExchangeWords = 32 * (1 + kMaxGroups / 32);
 constexpr size_t kSlotWords = kExchangeWord + kExchangeWords;
 constexpr uint64_t kStagePiece = 32ull << 20;    // host->device staging piece
+constexpr unsigned kResultSlots = 1024;          // pinned result words of the synchronous entry points
 // A stream's small scratch block: compute workspace | accumulators of the piece
 // kernel's self-planned form (kPlanMax records), all zero between calls.
 constexpr size_t kPlanRecsOffset = (kSlotWords * sizeof(uint32_t) + 255) / 256 * 256;
@@ -194,9 +195,11 @@ struct DeviceCtx {
     uint8_t* d_stage[2] = {nullptr, nullptr};
     uint32_t* d_state = nullptr;  // chained running state for staged pieces
     // Results of the synchronous entry points land in pinned host memory the
-    // GPU writes directly (no device->host copy command): 64 slots, 64 B apart.
+    // GPU writes directly (no device->host copy command): kResultSlots slots, 64 B
+    // apart, one per calling thread (a thread is inside one synchronous call at a
+    // time, so a slot is never shared by two calls in flight unless more than
+    // kResultSlots threads are inside such calls at once).
     uint32_t* h_results = nullptr;
-    std::atomic<unsigned> h_next{0};
     hipStream_t copy_stream = nullptr, work_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     // pinned bounce ring for pageable input
@@ -320,7 +323,7 @@ int init_ctx(DeviceCtx* c, int device) {  // the device is current
     SIFT_HIP(hipMalloc(&c->d_state, 256));
     // This device's address of the static scratch array (this device is current).
     SIFT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&c->static_scratch), HIP_SYMBOL(scratch)));
-    SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), 64 * 64, hipHostMallocDefault));
+    SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), kResultSlots * 64, hipHostMallocDefault));
     return SIFT_OK;
 }
 
@@ -493,8 +496,10 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     return SIFT_OK;
 }
 
+std::atomic<unsigned> g_thread_ids{0};
 volatile uint32_t* result_slot(DeviceCtx* c) {
-    return c->h_results + (size_t)(c->h_next.fetch_add(1) % 64) * 16;
+    static thread_local const unsigned my_id = g_thread_ids.fetch_add(1);
+    return c->h_results + (size_t)(my_id % kResultSlots) * 16;
 }
 
 // True when `stream` is being captured into a graph.  The library's own scratch
