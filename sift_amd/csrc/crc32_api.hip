@@ -83,7 +83,14 @@ const X2nTable& x2n() {
 // core copies slower than the link carries.
 constexpr int kBounceSlots = 4;
 constexpr size_t kBounceSlotBytes = 8ull << 20;
-constexpr uint64_t kBounceMin = 4ull << 20;  // below this the plain staged copy is as fast and simpler
+#ifndef SIFT_BOUNCE_MIN_KIB
+#define SIFT_BOUNCE_MIN_KIB 512
+#endif
+#ifndef SIFT_SMALL_HOST_MAX_KIB
+#define SIFT_SMALL_HOST_MAX_KIB 512
+#endif
+constexpr uint64_t kBounceMin = (uint64_t)SIFT_BOUNCE_MIN_KIB << 10;  // above the small path: host threads fill the pinned ring (the staged-copy path remains for SIFT_TUNE_HOST_COPY_THREADS = 0)
+constexpr uint64_t kSmallHostMax = (uint64_t)SIFT_SMALL_HOST_MAX_KIB << 10;  // up to this the caller's thread copies into a pinned slot itself
 
 class CopyCrew {
    public:
@@ -324,6 +331,9 @@ int init_ctx(DeviceCtx* c, int device) {  // the device is current
     // This device's address of the static scratch array (this device is current).
     SIFT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&c->static_scratch), HIP_SYMBOL(scratch)));
     SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_results), kResultSlots * 64, hipHostMallocDefault));
+    // Once per device: the tables are in place before any stream (non-blocking ones
+    // do not wait for the null stream's copies) launches a kernel that reads them.
+    SIFT_HIP(hipDeviceSynchronize());
     return SIFT_OK;
 }
 
@@ -402,7 +412,7 @@ void combine_mats(DeviceCtx* c, int64_t tpg, int groups, CombineMats* out) {
 // Geometry + launch of one compute(state, buf) over device memory.
 int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, const void* d_buf,
                    uint64_t len, uint32_t xor_out, uint32_t* d_out, uint32_t* workspace,
-                   hipStream_t stream) {
+                   hipStream_t stream, uint32_t tag = 0) {
     if (!d_out) {
         g_last_error = "d_out is NULL";
         return SIFT_ERR_INVALID_ARG;
@@ -419,6 +429,7 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     std::memset(&f, 0, sizeof(f));
     f.xor_out = xor_out;
     f.out = d_out;
+    f.tag = tag;
 
     if (len < 32) {
         // Too short to hold the folded state safely inside whole vectors: one
@@ -500,6 +511,48 @@ std::atomic<unsigned> g_thread_ids{0};
 volatile uint32_t* result_slot(DeviceCtx* c) {
     static thread_local const unsigned my_id = g_thread_ids.fetch_add(1);
     return c->h_results + (size_t)(my_id % kResultSlots) * 16;
+}
+
+// A tag no other call in flight carries (never 0).
+std::atomic<uint32_t> g_result_tags{0};
+uint32_t next_tag() {
+    uint32_t t = g_result_tags.fetch_add(1) + 1u;
+    while (t == 0u) t = g_result_tags.fetch_add(1) + 1u;
+    return t;
+}
+
+// Waits for the kernel's 8-byte store (tag << 32 | result) into the pinned slot.
+// The store is the last thing the call's last kernel does, and the GPU's writes to
+// coherent pinned memory are visible to the host as they land; polling for it
+// returns several microseconds before hipStreamSynchronize would (completion
+// signal, wake-up).  The stream is asked now and then, so that a failed launch or
+// a faulting kernel ends the wait with its error instead of hanging it.
+int wait_result(hipStream_t stream, volatile uint32_t* slot, uint32_t tag, uint32_t* out) {
+    volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(slot);
+    for (unsigned spin = 1;; ++spin) {
+        const unsigned long long v = *word;
+        if ((uint32_t)(v >> 32) == tag) {
+            *out = (uint32_t)v;
+            return SIFT_OK;
+        }
+        if ((spin & 0x3FFu) == 0) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) {  // everything has run: the store is at most in flight to the host
+                SIFT_HIP(hipStreamSynchronize(stream));
+                const unsigned long long w = *word;
+                if ((uint32_t)(w >> 32) != tag) {
+                    g_last_error = "the kernel finished without storing its result";
+                    return SIFT_ERR_HIP;
+                }
+                *out = (uint32_t)w;
+                return SIFT_OK;
+            }
+            if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 // True when `stream` is being captured into a graph.  The library's own scratch
@@ -783,11 +836,10 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf
     uint32_t* ws = nullptr;
     if ((rc = stream_workspace(c, s, &ws)) != SIFT_OK) return rc;
     volatile uint32_t* res = result_slot(c);
-    rc = launch_compute(c, state, nullptr, d_buf, len, 0u, const_cast<uint32_t*>(res), ws, s);
+    const uint32_t tag = next_tag();
+    rc = launch_compute(c, state, nullptr, d_buf, len, 0u, const_cast<uint32_t*>(res), ws, s, tag);
     if (rc != SIFT_OK) return rc;
-    SIFT_HIP(hipStreamSynchronize(s));
-    *out = *res;
-    return SIFT_OK;
+    return wait_result(s, res, tag, out);
 }
 
 int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_t len,
@@ -812,6 +864,7 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     uint32_t* ws = nullptr;
     if ((rc = stream_workspace(c, c->work_stream, &ws)) != SIFT_OK) return rc;
     volatile uint32_t* res = result_slot(c);
+    const uint32_t tag = next_tag();  // carried by the call's last launch
 
     // Pinned (hipHostMalloc / hipHostRegister) input is device-addressable: the
     // tile kernel streams it over PCIe directly, each byte crossing once, with
@@ -821,13 +874,21 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
         if (hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeHost &&
             attr.devicePointer != nullptr) {
             rc = launch_compute(c, state, nullptr, attr.devicePointer, len, 0u,
-                                const_cast<uint32_t*>(res), ws, c->work_stream);
+                                const_cast<uint32_t*>(res), ws, c->work_stream, tag);
             if (rc != SIFT_OK) return rc;
-            SIFT_HIP(hipStreamSynchronize(c->work_stream));
-            *out = *res;
-            return SIFT_OK;
+            return wait_result(c->work_stream, res, tag, out);
         }
         (void)hipGetLastError();  // an unregistered pointer is not an error here
+    }
+    // Small pageable input: this thread copies it into the first pinned slot and the
+    // kernel reads it there -- no copy command (a pageable hipMemcpyAsync costs tens of
+    // microseconds before a byte moves).
+    if (len <= kSmallHostMax) {
+        if (len) std::memcpy(c->h_bounce, src, len);
+        rc = launch_compute(c, state, nullptr, c->d_bounce, len, 0u, const_cast<uint32_t*>(res), ws,
+                            c->work_stream, tag);
+        if (rc != SIFT_OK) return rc;
+        return wait_result(c->work_stream, res, tag, out);
     }
     // Running state lives in c->d_state between pieces; piece 0 starts from
     // the immediate.  Empty input still runs one (empty) launch so that the
@@ -865,7 +926,7 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
             c->crew->wait();  // piece `piece` is in its slot
             if (!last && (e = start_copy(piece + 1, off + n)) != hipSuccess) break;
             rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_bounce + slot_of(piece), n, 0u,
-                                last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream);
+                                last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream, last ? tag : 0u);
             if (rc != SIFT_OK) break;
             if ((e = hipEventRecord(c->bounce_read[piece % kBounceSlots], c->work_stream)) != hipSuccess) break;
             off += n;
@@ -877,9 +938,7 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
             (void)hipStreamSynchronize(c->work_stream);
             return rc != SIFT_OK ? rc : fail_hip(e, "pinned bounce ring");
         }
-        SIFT_HIP(hipStreamSynchronize(c->work_stream));
-        *out = *res;
-        return SIFT_OK;
+        return wait_result(c->work_stream, res, tag, out);
     }
     // An error in the middle leaves copies from the caller's buffer in flight:
     // drain both streams before handing the buffer back.
@@ -904,16 +963,14 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
         SIFT_STAGE(hipStreamWaitEvent(c->work_stream, c->copied[b], 0));
         const bool last = off + n >= len;
         rc = launch_compute(c, state, piece ? c->d_state : nullptr, c->d_stage[b], n, 0u,
-                            last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream);
+                            last ? const_cast<uint32_t*>(res) : c->d_state, ws, c->work_stream, last ? tag : 0u);
         if (rc != SIFT_OK) return bail(rc);
         SIFT_STAGE(hipEventRecord(c->consumed[b], c->work_stream));
         off += n;
         ++piece;
     } while (off < len);
 #undef SIFT_STAGE
-    SIFT_HIP(hipStreamSynchronize(c->work_stream));
-    *out = *res;
-    return SIFT_OK;
+    return wait_result(c->work_stream, res, tag, out);
 }
 
 void sift_digest_new(sift_digest* d, int device) {

@@ -104,6 +104,10 @@ struct FinalArgs {
     uint32_t xor_out;            // 0, or 0xFFFFFFFF to finalize (Chunk::compute_crc)
     uint32_t* out;
     int32_t groups;
+    // Synchronous entry points: `out` is an 8-byte slot in pinned host memory and the
+    // result goes out as ONE 8-byte store (tag << 32 | result), which the calling thread
+    // polls for instead of waiting for the stream (0: plain 4-byte store).
+    uint32_t tag;
 };
 
 // Row k of level s: z^(2^s) * x^k, z = x^(8 * tiles_per_group * kTileBytes).

@@ -140,7 +140,11 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t r) {
 __device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f) {
     uint32_t r = body;
     for (uint32_t i = 0; i < f.tail_len; ++i) r = crc_step_byte(r, f.tail[i]);
-    *f.out = r ^ f.xor_out;
+    if (f.tag)
+        *reinterpret_cast<volatile unsigned long long*>(f.out) =
+            ((unsigned long long)f.tag << 32) | (unsigned long long)(r ^ f.xor_out);
+    else
+        *f.out = r ^ f.xor_out;
 }
 
 }  // namespace
