@@ -151,16 +151,23 @@ int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t 
                                      const void *d_buf, uint64_t len, uint32_t *d_out,
                                      void *stream);
 
-/* Same as sift_crc32_compute_device, then waits and returns the new state through `*out` (host). */
+/* Same as sift_crc32_compute_device, then waits and returns the new state through `*out` (host).
+ * The wait is a poll of a pinned 8-byte word (tag | result) that the call's last kernel stores
+ * and that belongs to the calling thread, not a hipStreamSynchronize: the call returns when the
+ * result is there (a few microseconds earlier), with the stream's error if the kernel failed.
+ * Work queued on `stream` BEFORE the call has finished by then; the call's own kernel has done
+ * all its reads of `d_buf` and is at most retiring. */
 int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf, uint64_t len,
                                    uint32_t *out, void *stream);
 
 /* Host-resident input, reduced on the GPU; returns the new state through
  * `*out`.  Pinned memory (hipHostMalloc / hipHostRegister) is read by the
- * kernel in place over PCIe.  Pageable memory of 4 MiB and more is copied by a
- * few host threads into a ring of pinned 8 MiB slots which the kernel reads in
- * place, slot k+1 being filled while slot k is read; smaller pageable inputs
- * are staged with hipMemcpyAsync.  This is the signature the reference's
+ * kernel in place over PCIe.  Pageable memory of up to 512 KiB is copied by the
+ * calling thread into a pinned slot and read there; more than that is copied by
+ * a few host threads into a ring of pinned 8 MiB slots which the kernel reads in
+ * place, slot k+1 being filled while slot k is read (with
+ * SIFT_TUNE_HOST_COPY_THREADS = 0: staged with hipMemcpyAsync instead).  Calls
+ * on one device are serialised.  This is the signature the reference's
  * compute(crc, buf) maps to one-to-one. */
 int sift_crc32_compute_host(int device, uint32_t state, const void *buf, uint64_t len,
                             uint32_t *out);
