@@ -154,7 +154,8 @@ int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t 
 /* Same as sift_crc32_compute_device, then waits and returns the new state through `*out` (host).
  * The wait is a poll of a pinned 8-byte word (tag | result) that the call's last kernel stores
  * and that belongs to the calling thread, not a hipStreamSynchronize: the call returns when the
- * result is there (a few microseconds earlier), with the stream's error if the kernel failed.
+ * result is there (a few microseconds earlier); after 60 us of polling it waits for the stream
+ * instead, which is also where a failed kernel's error surfaces.
  * Work queued on `stream` BEFORE the call has finished by then; the call's own kernel has done
  * all its reads of `d_buf` and is at most retiring. */
 int sift_crc32_compute_device_sync(int device, uint32_t state, const void *d_buf, uint64_t len,

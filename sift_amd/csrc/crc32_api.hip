@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <thread>
 #include <string>
@@ -525,34 +526,34 @@ uint32_t next_tag() {
 // The store is the last thing the call's last kernel does, and the GPU's writes to
 // coherent pinned memory are visible to the host as they land; polling for it
 // returns several microseconds before hipStreamSynchronize would (completion
-// signal, wake-up).  The stream is asked now and then, so that a failed launch or
-// a faulting kernel ends the wait with its error instead of hanging it.
+// signal, wake-up).  Short calls are what this is for: after kPollNs of polling
+// the thread stops burning its core and waits for the stream instead, which also
+// is where a failed launch or a faulting kernel surfaces with its error.
+constexpr long long kPollNs = 60 * 1000;
 int wait_result(hipStream_t stream, volatile uint32_t* slot, uint32_t tag, uint32_t* out) {
     volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(slot);
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 1;; ++spin) {
         const unsigned long long v = *word;
         if ((uint32_t)(v >> 32) == tag) {
             *out = (uint32_t)v;
             return SIFT_OK;
         }
-        if ((spin & 0x3FFu) == 0) {
-            const hipError_t e = hipStreamQuery(stream);
-            if (e == hipSuccess) {  // everything has run: the store is at most in flight to the host
-                SIFT_HIP(hipStreamSynchronize(stream));
-                const unsigned long long w = *word;
-                if ((uint32_t)(w >> 32) != tag) {
-                    g_last_error = "the kernel finished without storing its result";
-                    return SIFT_ERR_HIP;
-                }
-                *out = (uint32_t)w;
-                return SIFT_OK;
-            }
-            if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
-        }
+        if ((spin & 63u) == 0 &&
+            std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kPollNs)
+            break;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
+    SIFT_HIP(hipStreamSynchronize(stream));
+    const unsigned long long w = *word;
+    if ((uint32_t)(w >> 32) != tag) {
+        g_last_error = "the kernel finished without storing its result";
+        return SIFT_ERR_HIP;
+    }
+    *out = (uint32_t)w;
+    return SIFT_OK;
 }
 
 // True when `stream` is being captured into a graph.  The library's own scratch
