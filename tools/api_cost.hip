@@ -3,7 +3,7 @@
 // queries, capture query, event record / synchronize, kernel launch), which is
 // what decides how the small-call paths are built ("Crossover").
 //   build: make -C tools bin/api_cost
-#pragma clang diagnostic ignored "-Wunused-result"
+#pragma clang diagnostic ignored "-Wunused-value"
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
