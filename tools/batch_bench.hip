@@ -138,6 +138,37 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    // Synchronous single calls through the C ABI (no Python in between): device-resident,
+    // pageable host and pinned host input
+    if (!only_chunk) {
+        std::vector<uint8_t> hbuf(1 << 20, 0x5A);
+        uint8_t* pin = nullptr;
+        CK(hipHostMalloc(reinterpret_cast<void**>(&pin), 1 << 20, hipHostMallocDefault));
+        memset(pin, 0x5A, 1 << 20);
+        for (size_t size : {(size_t)4, (size_t)4096, (size_t)65536, (size_t)1 << 20}) {
+            double us[3] = {0, 0, 0};
+            for (int kind = 0; kind < 3; ++kind) {
+                uint32_t r = 0;
+                const int reps = 300;
+                for (int i = 0; i < 5; ++i) {
+                    if (kind == 0) SK(sift_crc32_compute_device_sync(0, 0xFFFFFFFFu, blob, size, &r, s));
+                    else SK(sift_crc32_compute_host(0, 0xFFFFFFFFu, kind == 1 ? hbuf.data() : pin, size, &r));
+                }
+                const double t0 = now();
+                for (int i = 0; i < reps; ++i) {
+                    if (kind == 0) SK(sift_crc32_compute_device_sync(0, 0xFFFFFFFFu, blob, size, &r, s));
+                    else SK(sift_crc32_compute_host(0, 0xFFFFFFFFu, kind == 1 ? hbuf.data() : pin, size, &r));
+                }
+                us[kind] = (now() - t0) / reps * 1e6;
+            }
+            printf("%s {\"kind\": \"sync_call\", \"bytes\": %zu, \"device_us\": %.2f, \"pageable_host_us\": %.2f, "
+                   "\"pinned_host_us\": %.2f}",
+                   first ? "" : ",\n", size, us[0], us[1], us[2]);
+            first = false;
+            fflush(stdout);
+        }
+        CK(hipHostFree(pin));
+    }
     // Chunk::read on ONE serialized chunk: length only in its header
     for (size_t n : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20, ((size_t)1 << 30) - 16}) {
         if (only_chunk && n != only_n) continue;
