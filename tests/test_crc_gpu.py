@@ -94,6 +94,21 @@ def test_host_buffer_path(gpu, oracle):
     # covered by tools/host_input_sweep.py 0 (a process of its own), not here
 
 
+def test_host_input_random_sizes_vs_zlib(gpu):
+    # both sides of the 512 KiB switch between the caller-copied pinned slot and the
+    # threaded ring, odd starts, chained registers
+    rng = np.random.default_rng(4242)
+    big = rng.integers(0, 256, size=3 << 20, dtype=np.uint8)
+    for k in range(200):
+        n = int(rng.integers(0, 1 << int(rng.integers(1, 22))))
+        off = int(rng.integers(0, big.size - n))
+        piece = big[off:off + n]
+        cut = int(rng.integers(0, n + 1))
+        state = gpu.compute(0xFFFFFFFF, piece[:cut])
+        state = gpu.compute(state, piece[cut:])
+        assert state == zlib.crc32(piece.tobytes()) ^ 0xFFFFFFFF, (k, off, n, cut)
+
+
 def test_synchronous_calls_from_many_threads(gpu, oracle):
     # The synchronous entry points poll a pinned 8-byte slot (tag | result) that belongs to the
     # calling thread: 16 threads, device-resident and host-resident inputs, 100 calls each.
