@@ -99,7 +99,7 @@ enum {
                                     0 (default) = 256 KiB for n >= 4096 items, else 32 KiB */
     SIFT_TUNE_BATCH_PIECE_LOG2 = 4, /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
     SIFT_TUNE_HOST_COPY_THREADS = 6, /* host threads (incl. the caller's) that fill the pinned bounce
-                                    ring for pageable input of 4 MiB and more, 1..16 (default 4);
+                                    ring for pageable input of more than 512 KiB, 1..16 (default 4);
                                     0: always the staged hipMemcpyAsync path.  Set before the first
                                     host-input call on a device. */
     SIFT_TUNE_BATCH_PLAN = 5     /* 1 (default): up to 64 items (not whole documents) go straight to the
