@@ -367,3 +367,16 @@ def test_many_small_host_descriptor_calls_in_a_row(gpu, oracle):
         if k % 7 == 0:
             want = np.array([oracle.compute(0xFFFFFFFF, blob[o:o + ln]) for o, ln in zip(offs, lens)], dtype=np.uint32)
             assert (got == want).all(), k
+
+
+def test_randomised_rounds(gpu, oracle):
+    # tests/fuzz_batch.py: random chunk / save-file streams with random corruptions, batch
+    # sizes on both sides of every path switch, descriptors on the host or in HBM
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_batch", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_batch.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    for seed in range(7000, 7010):
+        fuzz.one_round(seed)
