@@ -62,14 +62,15 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> off(1 << 20), len(1 << 20);
 
     // batch_bench chunk <bytes>: only Chunk::read on one chunk of that many data bytes (for rocprofv3)
-    const bool only_chunk = argc >= 3 && !strcmp(argv[1], "chunk");
+    const bool only_items = argc >= 3 && !strcmp(argv[1], "items");  // batch_bench items <bytes>: one crc_batch size (for rocprofv3 --pmc)
+    const bool only_chunk = (argc >= 3 && !strcmp(argv[1], "chunk")) || only_items;
     const size_t only_n = only_chunk ? strtoull(argv[2], nullptr, 0) : 0;
     printf("{\"rows\": [\n");
     bool first = true;
     // plain buffers back to back in the blob, descriptors in HBM and on the host
     const size_t sizes[] = {64, 100, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
     for (size_t size : sizes) {
-        if (only_chunk) break;
+        if (only_items ? size != only_n : only_chunk) continue;
         const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
         for (uint32_t i = 0; i < n; ++i) {
             off[i] = (uint64_t)i * size;
@@ -77,7 +78,7 @@ int main(int argc, char** argv) {
         }
         CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
-        for (int where = 0; where < 2; ++where) {
+        for (int where = 0; where < (only_items ? 1 : 2); ++where) {
             const uint64_t* po = where ? off.data() : d_off;
             const uint64_t* pl = where ? len.data() : d_len;
             for (int i = 0; i < 3; ++i)
