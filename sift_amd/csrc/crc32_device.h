@@ -43,8 +43,22 @@ constexpr int kUnroll = SIFT_UNROLL;        // tiles in flight per lane, twice (
 constexpr int kGroupsPerCu = SIFT_GROUPS_PER_CU;  // resident workgroups per CU the LDS budget allows
 static_assert(kReplLog2 > 0, "SIFT_REPL must be 8, 16 or 32");
 static_assert(kThreads % 64 == 0 && kThreads >= 64 && kThreads <= 1024, "SIFT_THREADS");
-constexpr int kGroupRepl = 2;                // LDS copies of the batch kernel's group-path Horner table
-constexpr int kGroupReplLog2 = 1;
+// LDS copies of the batch kernel's tables (SQ counters, profiles/r02_batch_pmc.json: with 2
+// copies of the group path's Horner table and 1 of the x^32 table, two thirds of the LDS
+// cycles at 1-3 KB items were bank conflicts).  160 KiB hold: wave path's table kWaveRepl
+// copies, group path's kGroupRepl, x^32 kXRepl, the lane-join tables and T8 one each.
+#ifndef SIFT_WAVE_REPL_LOG2
+#define SIFT_WAVE_REPL_LOG2 4
+#endif
+#ifndef SIFT_GROUP_REPL_LOG2
+#define SIFT_GROUP_REPL_LOG2 3
+#endif
+#ifndef SIFT_X_REPL_LOG2
+#define SIFT_X_REPL_LOG2 3
+#endif
+constexpr int kWaveReplLog2 = SIFT_WAVE_REPL_LOG2, kWaveRepl = 1 << kWaveReplLog2;
+constexpr int kGroupReplLog2 = SIFT_GROUP_REPL_LOG2, kGroupRepl = 1 << kGroupReplLog2;
+constexpr int kXReplLog2 = SIFT_X_REPL_LOG2, kXRepl = 1 << kXReplLog2;
 constexpr int kMaxGroups = 1024;            // workgroups one call may launch
 constexpr int kTreeLevels = 10;             // log2(kMaxGroups)
 

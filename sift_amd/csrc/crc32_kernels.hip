@@ -57,6 +57,23 @@ __device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
            ldsX[768 + (v >> 24)];
 }
 
+// The same two multiplies from tables with 2^RLOG2 copies of every entry in a row
+// (the batch kernel's): lane-chosen copy `lr` < 2^RLOG2.
+template <int RLOG2, typename P>
+__device__ __forceinline__ uint32_t mul_tab(uint32_t a, P tab, uint32_t lr) {
+    constexpr int T = 256 << RLOG2;  // words per byte-position table
+    const uint32_t i0 = ((a & 0xffu) << RLOG2) + lr;
+    const uint32_t i1 = (((a >> 8) & 0xffu) << RLOG2) + lr;
+    const uint32_t i2 = (((a >> 16) & 0xffu) << RLOG2) + lr;
+    const uint32_t i3 = ((a >> 24) << RLOG2) + lr;
+    return tab[i0] ^ tab[T + i1] ^ tab[2 * T + i2] ^ tab[3 * T + i3];
+}
+template <int RLOG2, typename P>
+__device__ __forceinline__ void horner_tab(u32x4& acc, const u32x4 w, P tab, uint32_t lr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = mul_tab<RLOG2>(acc[c], tab, lr) ^ w[c];
+}
+
 // One byte of the reference's recurrence WITH its table (crc.rs:31):
 // c = CRC_TABLE[(c ^ byte) & 0xff] ^ (c >> 8).
 template <typename P>
@@ -561,6 +578,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
             for (uint32_t i = 0; i < (uint32_t)len; ++i) r = crc_step_byte(r, ptr[i]);
         return __shfl(r, 0, 64);
     }
+    const uint32_t lw = lane32 & (uint32_t)(kWaveRepl - 1), lx = lane32 & (uint32_t)(kXRepl - 1);  // table copies
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
     const int64_t nvec = (int64_t)(v1 - v0);  // >= 1, body >= 17 bytes
@@ -588,7 +606,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     const u32x4* p = vbase + vi;
     if (left > 0) {
         const u32x4 w = fold_state(*p, vi, h, state);
-        horner_step(acc, w, ldsY, lane32);
+        horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
         p += 64;
         --left;
     }
@@ -601,21 +619,21 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
             const u32x4 n0 = __builtin_nontemporal_load(p);
             const u32x4 n1 = __builtin_nontemporal_load(p + 64);
             p += 128;
-            horner_step(acc, c0, ldsY, lane32);
-            horner_step(acc, c1, ldsY, lane32);
+            horner_tab<kWaveReplLog2>(acc, c0, ldsY, lw);
+            horner_tab<kWaveReplLog2>(acc, c1, ldsY, lw);
             c0 = n0;
             c1 = n1;
         }
-        horner_step(acc, c0, ldsY, lane32);
-        horner_step(acc, c1, ldsY, lane32);
+        horner_tab<kWaveReplLog2>(acc, c0, ldsY, lw);
+        horner_tab<kWaveReplLog2>(acc, c1, ldsY, lw);
     }
     if (left > 0) {
         const u32x4 w = __builtin_nontemporal_load(p);
-        horner_step(acc, w, ldsY, lane32);
+        horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
     }
     uint32_t r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+    for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
     r = gf2_mulmod(r, aw);
     r = wave_xor(r);
     // trailing bytes: every lane walks them alike (no divergence, no broadcast)
@@ -623,26 +641,8 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     return r;
 }
 
-// acc * x^(8*256): the group path's Horner constant.  The table is replicated four
-// times only (LDS has 28 KiB left beside the wave path's): entry (k, b) for copy r
-// lives at word ((k*256 + b) * 4 + r), lane l uses r = l & 3.  Lookups conflict
-// about two ways on average, which this latency-bound path does not notice.
-template <typename P>
-__device__ __forceinline__ uint32_t mul_yg(uint32_t a, P ldsG, uint32_t l4) {
-    constexpr int T = 256 * kGroupRepl;
-    const uint32_t i0 = ((a & 0xffu) << kGroupReplLog2) + l4;
-    const uint32_t i1 = (((a >> 8) & 0xffu) << kGroupReplLog2) + l4;
-    const uint32_t i2 = (((a >> 16) & 0xffu) << kGroupReplLog2) + l4;
-    const uint32_t i3 = ((a >> 24) << kGroupReplLog2) + l4;
-    return ldsG[i0] ^ ldsG[T + i1] ^ ldsG[2 * T + i2] ^ ldsG[3 * T + i3];
-}
-
-template <typename P>
-__device__ __forceinline__ void horner_g(u32x4& acc, const u32x4 w, P ldsG, uint32_t l4) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = mul_yg(acc[c], ldsG, l4) ^ w[c];
-}
-
+// acc * x^(8*256) is the group path's Horner constant (mul_tab / horner_tab with the
+// kGroupRepl-copy table ldsG).
 // CRC of a span of 32 .. kGroupMax bytes by ONE 16-LANE GROUP, four spans per wave
 // at a time: the wave kernel's algebra at group scale.  A tile is 16 lanes x 16 B
 // = 256 B, the Horner step multiplies by x^(8*256), tiles are aligned to the end
@@ -660,7 +660,8 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
     typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
     const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
-    const uint32_t l16 = lane & 15u, gbase = lane & 48u, l4 = lane & (uint32_t)(kGroupRepl - 1);
+    const uint32_t l16 = lane & 15u, gbase = lane & 48u;
+    const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1), lx = lane & (uint32_t)(kXRepl - 1);  // table copies
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
     const int32_t nvec = (int32_t)(v1 - v0);  // 2..255
@@ -683,7 +684,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         }
         if (ntile > 1) {
             w1 = fold_state(w1, vi + 16, h, state);
-            horner_g(acc, w1, ldsG, l4);
+            horner_tab<kGroupReplLog2>(acc, w1, ldsG, l4);
         }
     }
     vi += 32;
@@ -693,8 +694,8 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         const bool ha = t < ntile, hb = t + 1 < ntile;
         if (ha) wa = __builtin_nontemporal_load(vbase + vi);
         if (hb) wb = __builtin_nontemporal_load(vbase + vi + 16);
-        if (ha) horner_g(acc, wa, ldsG, l4);
-        if (hb) horner_g(acc, wb, ldsG, l4);
+        if (ha) horner_tab<kGroupReplLog2>(acc, wa, ldsG, l4);
+        if (hb) horner_tab<kGroupReplLog2>(acc, wb, ldsG, l4);
     }
     // the lane's four words, then the sixteen lanes joined pairwise: at step j the
     // lane whose bit j is clear holds the earlier 2^j vectors, multiplies by
@@ -705,7 +706,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
     uint32_t r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = mul_x32(r ^ acc[c], ldsX);
+    for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
 #pragma unroll
     for (int j = 0; j < 4; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
@@ -920,21 +921,24 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
-    constexpr int kGWords = 4 * 256 * kGroupRepl;
+    constexpr int kWWords = 4 * 256 * kWaveRepl, kGWords = 4 * 256 * kGroupRepl, kXrWords = 4 * 256 * kXRepl;
     constexpr int kKWords = 4 * 4 * 256, kT8Words = 256;
-    __shared__ uint32_t lds[kYWords + kGWords + kXWords + kKWords + kT8Words];  // 157 of 160 KiB
+    static_assert((kWWords + kGWords + kXrWords + kKWords + kT8Words) * 4 <= 160 * 1024, "LDS");
+    __shared__ uint32_t lds[kWWords + kGWords + kXrWords + kKWords + kT8Words];  // 145 of 160 KiB
     uint32_t* ldsY = lds;
-    uint32_t* ldsG = lds + kYWords;
+    uint32_t* ldsG = lds + kWWords;
     uint32_t* ldsX = ldsG + kGWords;
-    uint32_t* ldsK = ldsX + kXWords;
+    uint32_t* ldsK = ldsX + kXrWords;
     uint32_t* ldsT8 = ldsK + kKWords;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
 #pragma unroll 16
-    for (int i = tid; i < kYWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kReplLog2];
+    for (int i = tid; i < kWWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kWaveReplLog2];
+#pragma unroll 8
     for (int i = tid; i < kGWords; i += kThreads) ldsG[i] = b.tabs->Y256[i >> kGroupReplLog2];
-    for (int i = tid; i < kXWords; i += kThreads) ldsX[i] = b.tabs->X[i];
+#pragma unroll 8
+    for (int i = tid; i < kXrWords; i += kThreads) ldsX[i] = b.tabs->X[i >> kXReplLog2];
     for (int i = tid; i < kKWords; i += kThreads) ldsK[i] = (&b.tabs->K[0][0])[i];
     for (int i = tid; i < kT8Words; i += kThreads) ldsT8[i] = b.tabs->T8[i];
     const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
