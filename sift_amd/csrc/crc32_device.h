@@ -51,10 +51,10 @@ static_assert(kThreads % 64 == 0 && kThreads >= 64 && kThreads <= 1024, "SIFT_TH
 #define SIFT_WAVE_REPL_LOG2 4
 #endif
 #ifndef SIFT_GROUP_REPL_LOG2
-#define SIFT_GROUP_REPL_LOG2 3
+#define SIFT_GROUP_REPL_LOG2 4
 #endif
 #ifndef SIFT_X_REPL_LOG2
-#define SIFT_X_REPL_LOG2 3
+#define SIFT_X_REPL_LOG2 1
 #endif
 constexpr int kWaveReplLog2 = SIFT_WAVE_REPL_LOG2, kWaveRepl = 1 << kWaveReplLog2;
 constexpr int kGroupReplLog2 = SIFT_GROUP_REPL_LOG2, kGroupRepl = 1 << kGroupReplLog2;

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     constexpr int kWWords = 4 * 256 * kWaveRepl, kGWords = 4 * 256 * kGroupRepl, kXrWords = 4 * 256 * kXRepl;
     constexpr int kKWords = 4 * 4 * 256, kT8Words = 256;
     static_assert((kWWords + kGWords + kXrWords + kKWords + kT8Words) * 4 <= 160 * 1024, "LDS");
-    __shared__ uint32_t lds[kWWords + kGWords + kXrWords + kKWords + kT8Words];  // 145 of 160 KiB
+    __shared__ uint32_t lds[kWWords + kGWords + kXrWords + kKWords + kT8Words];  // 153 of 160 KiB
     uint32_t* ldsY = lds;
     uint32_t* ldsG = lds + kWWords;
     uint32_t* ldsX = ldsG + kGWords;
