@@ -569,6 +569,20 @@ __device__ __forceinline__ u32x4 fold_state(u32x4 w, int64_t vi, uint32_t h, uin
     return w;
 }
 
+// The same for a vector known to be vector 0 or 1, with shifts instead of a byte loop
+// (the group paths, where this runs once per pass): the state is a 32-bit word laid at
+// byte h of vectors 0|1, i.e. at byte sh = h - 16 * vi of this one, straddling words
+// sh >> 2 and (sh >> 2) + 1.
+__device__ __forceinline__ u32x4 fold_state_word(u32x4 w, int32_t vi, uint32_t h, uint32_t state) {
+    const int32_t sh = (int32_t)h - 16 * vi;  // -16 .. 15; under -3 nothing lands here
+    const uint32_t bs = 8u * ((uint32_t)sh & 3u);
+    const uint32_t lo = state << bs, hi = bs ? state >> (32u - bs) : 0u;
+    const int32_t wi = sh >> 2;  // -4 .. 3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] ^= (wi == c ? lo : 0u) ^ (wi + 1 == c ? hi : 0u);
+    return w;
+}
+
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
                                              const uint32_t* ldsY, const uint32_t* ldsX, const uint32_t* ldsT8,
                                              uint32_t lane, uint32_t lane32, uint32_t aw) {
@@ -583,7 +597,12 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
     const int64_t nvec = (int64_t)(v1 - v0);  // >= 1, body >= 17 bytes
     const uint32_t h = (uint32_t)(addr & 15u);
-    const u32x4* vbase = reinterpret_cast<const u32x4*>(v0 << 4);
+    // The address came through lane shuffles as an integer: say that it is global memory,
+    // or the loads below are flat loads, which count as LDS traffic too -- every wait for
+    // a table lookup then waits for the data in flight as well.
+    typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
+    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
+    const GlobalVec vbase = (GlobalVec)(v0 << 4);
     const int64_t ntile = (nvec + 63) >> 6;
     int64_t vi = nvec - ntile * 64 + (int64_t)lane;  // tiles aligned to the end of the body
 
@@ -596,14 +615,14 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // the data, instead of one lane fetching them after everything else
     const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
     uint32_t tb = 0;
-    if (lane < tail_len) tb = reinterpret_cast<const uint8_t*>(v1 << 4)[lane];
+    if (lane < tail_len) tb = ((GlobalByte)(v1 << 4))[lane];
     if (vi >= 0) {
         if (vi == 0 && h) acc = mask_head(acc, h);
         acc = fold_state(acc, vi, h, state);
     }
     vi += 64;
     int64_t left = ntile - 1;
-    const u32x4* p = vbase + vi;
+    GlobalVec p = vbase + vi;
     if (left > 0) {
         const u32x4 w = fold_state(*p, vi, h, state);
         horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
@@ -641,78 +660,153 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     return r;
 }
 
-// acc * x^(8*256) is the group path's Horner constant (mul_tab / horner_tab with the
-// kGroupRepl-copy table ldsG).
-// CRC of a span of 32 .. kGroupMax bytes by ONE 16-LANE GROUP, four spans per wave
-// at a time: the wave kernel's algebra at group scale.  A tile is 16 lanes x 16 B
-// = 256 B, the Horner step multiplies by x^(8*256), tiles are aligned to the end
-// of the body so only the first can be partial.  Every lane of the wave calls
-// this; `on` says whether the lane's group has a span.  The register over the
-// whole span comes back in lane 0 of the group.  Not inlined: inside the batch
-// kernel's item loop, beside the wave path, it pushed the kernel past 128 VGPRs
-// (15-43 spilled); as a call it costs a few instructions per four spans.
+// CRC of a span of 32 .. kGroupMax bytes by ONE GROUP OF GW LANES (8 or 4), 64/GW spans
+// per wave at a time: the wave kernel's algebra at group scale.  The body is cut into
+// tiles of GW vectors, aligned to its end so that only the first can be partial; lane l
+// of the group takes vector l of every tile.  A lane keeps 16/GW accumulators ("chains"):
+// the tiles, counted from the end, go to the chains round-robin, so that whatever GW is,
+// a chain steps over 16 vectors and every Horner step multiplies by x^(8*256) from the one
+// kGroupRepl-copy table (mul_tab / horner_tab on ldsG).  At the end a lane's chains are
+// joined with x^(128*GW) (the lane-join table of the same constant), then the lanes.
+// The work per byte is the same for every GW; what a narrow group saves is the work per
+// PASS (the x^32 fold, the lane join, the trailing bytes, the call), which 8 or 16 spans
+// share, and the lanes left idle by a span shorter than a tile.  (Round 2 began with
+// 16-lane groups, four spans a pass: 64-byte items 3.3x slower, 1 KiB items 15 %, mixed
+// 32..4080-byte items 5 %; nothing was faster.)  Every lane of the wave calls this; `on`
+// says whether the lane's group has a span.  The register over the whole span comes back
+// in lane 0 of the group.  Not inlined: inside the batch kernel's item loop, beside the
+// wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few instructions
+// per pass -- but the kernel around it can only keep what the callee leaves of the 128
+// registers, which is why the rounds below are written to stay near 50.
+template <int GW>
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
                                               const uint32_t* ldsG_, const uint32_t* ldsX_,
                                               const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
+    static_assert(GW == 8 || GW == 4, "group width");
+    constexpr int LG = GW == 8 ? 3 : 2;                 // log2(GW): steps of the lane join
+    constexpr int NCH = 16 / GW, LCH = 4 - LG;          // chains per lane
+    constexpr uint32_t TB = 16u / GW;                   // trailing bytes a lane fetches
     // A call passes generic pointers; say which memory they point into, or every
     // table lookup becomes a flat load that waits on both counters.
     typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
     typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
     const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
-    const uint32_t l16 = lane & 15u, gbase = lane & 48u;
+    const uint32_t lg = lane & (uint32_t)(GW - 1), gbase = lane & (uint32_t)(64 - GW);
     const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1), lx = lane & (uint32_t)(kXRepl - 1);  // table copies
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
     const int32_t nvec = (int32_t)(v1 - v0);  // 2..255
     const uint32_t h = (uint32_t)(addr & 15u);
     const GlobalVec vbase = (GlobalVec)(v0 << 4);
-    const int32_t ntile = on ? (nvec + 15) >> 4 : 0;
-    int32_t vi = nvec - ntile * 16 + (int32_t)l16;
+    const int32_t ntile = on ? (nvec + GW - 1) >> LG : 0;
     const uint32_t tail_len = on ? (uint32_t)((addr + len) & 15u) : 0u;
-    // Tile 0 (may start before vector 0) and tile 1 are peeled: the four state bytes
-    // land in vectors 0 and 1.
-    u32x4 acc = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
     uint32_t tb = 0;
-    if (on) {
-        if (vi >= 0) acc = vbase[vi];
-        if (ntile > 1) w1 = vbase[vi + 16];
-        if (l16 < tail_len) tb = ((GlobalByte)(v1 << 4))[l16];
-        if (vi >= 0) {
-            if (vi == 0 && h) acc = mask_head(acc, h);
-            acc = fold_state(acc, vi, h, state);
+    auto load_tail = [&]() {  // the group's trailing bytes, 16/GW a lane; issued behind the first vectors
+#pragma unroll
+        for (uint32_t k = 0; k < TB; ++k)
+            if (lg * TB + k < tail_len) tb |= (uint32_t)((GlobalByte)(v1 << 4))[lg * TB + k] << (8u * k);
+    };
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    {
+        // A round is one tile per chain; rounds are counted from the first (t = 0, the
+        // only one that can be short of tiles).  In round t chain c holds tile
+        // NCH * (nround - 1 - t) + c, counted from the END of the body, which is vectors
+        // nvec - GW * (tile + 1) .. + GW - 1.  Every load is unconditional (a vector the
+        // lane does not have is read at a clamped index and zeroed by a select): a load
+        // under a divergent branch makes the compiler wait for it on the spot, one memory
+        // latency per chain.  Within a round all loads are issued first and the chains
+        // are then stepped one after the other (scheduling barriers): interleaved by the
+        // compiler they took 70-100 registers, and a callee that big makes the kernel
+        // around it spill.  4-lane groups only take spans of one round (kGroup4Max <= 256
+        // bytes: at most 16 vectors at any alignment).
+        const int32_t nround = GW == 4 ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
+        const int32_t tile0 = NCH * (nround - 1);
+        const int32_t vi0 = nvec - GW * (tile0 + 1) + (int32_t)lg;  // round 0, chain c: vector vi0 - GW * c
+        // Vectors 0 and 1 need the head mask and the state bytes.  A lane holds at most
+        // one of them: in round 0, chain vi0 >> LG (its vector there is vi0 mod GW), or --
+        // when vector 0 is alone in its tile -- vector 1 in round 1, last chain.
+        const bool head0 = on && vi0 >= 0 && (vi0 & (GW - 1)) <= 1;
+        const bool head1 = GW != 4 && on && vi0 == 1 - GW;
+        const int32_t hvi = head1 ? 1 : (vi0 & (GW - 1)), hc = vi0 >> LG;
+        const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+        const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, h, state);
+        const u32x4 keep = hvi == 0 ? mask_head(ones, h) : ones;
+        u32x4 ch[NCH];
+        {
+            bool ex[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int32_t vi = vi0 - GW * c;
+                ex[c] = on && tile0 + c < ntile && vi >= 0;
+                ch[c] = vbase[ex[c] ? vi : 0];
+            }
+            load_tail();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bool hd = head0 && hc == c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t x = ex[c] ? ch[c][k] : 0u;
+                    ch[c][k] = hd ? (x & keep[k]) ^ delta[k] : x;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ntile > 1) {
-            w1 = fold_state(w1, vi + 16, h, state);
-            horner_tab<kGroupReplLog2>(acc, w1, ldsG, l4);
+        for (int32_t t = 1; GW != 4 && __any(t < nround); ++t) {
+            const bool ha = t < nround;
+            const int32_t vt = vi0 + 16 * t;  // chain c: vector vt - GW * c
+            u32x4 w[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(vbase + (ha ? vt - GW * c : 0));
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 1 && __any(head1)) {  // worked out again here: four registers fewer across the loop
+                const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, h, state);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[NCH - 1][k] ^= head1 ? d1[k] : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (ha) {  // two words at a time: half the lookups in flight, half the registers
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 2; k < 4; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the lane's chains: chain c is GW vectors (x^(128*GW), lane-join table LG) ahead
+        // of chain c - 1.  Steps no group of the wave needs are skipped (all zero so far).
+        acc = ch[NCH - 1];
+#pragma unroll
+        for (int c = NCH - 2; c >= 0; --c) {
+            if (__any(ntile > c + 1)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = mul_x32(acc[k], ldsK + LG * 1024);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
         }
     }
-    vi += 32;
-    // the rest two tiles at a time; groups with fewer tiles sit the iterations out
-    for (int32_t t = 2; __any(t < ntile); t += 2, vi += 32) {
-        u32x4 wa = {0u, 0u, 0u, 0u}, wb = {0u, 0u, 0u, 0u};
-        const bool ha = t < ntile, hb = t + 1 < ntile;
-        if (ha) wa = __builtin_nontemporal_load(vbase + vi);
-        if (hb) wb = __builtin_nontemporal_load(vbase + vi + 16);
-        if (ha) horner_tab<kGroupReplLog2>(acc, wa, ldsG, l4);
-        if (hb) horner_tab<kGroupReplLog2>(acc, wb, ldsG, l4);
-    }
-    // the lane's four words, then the sixteen lanes joined pairwise: at step j the
+    // the lane's four words, then the GW lanes joined pairwise: at step j the
     // lane whose bit j is clear holds the earlier 2^j vectors, multiplies by
     // x^(128 * 2^j) (four lookups in K[j]) and takes in its partner's.  Lane 0 of the
     // group ends up with the body's register.  (A 32-step register multiply by the
-    // lane's place, x^(128 * (15 - lane)), costs 7 instructions a bit; this path is
+    // lane's place, x^(128 * (GW - 1 - lane)), costs 7 instructions a bit; this path is
     // VALU-bound -- a wave64 instruction takes four cycles -- so lookups win.  Four
     // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
+    for (int j = 0; j < LG; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
     // meaningful register, the others walk along
     for (uint32_t i = 0; __any(i < tail_len); ++i) {
-        const uint32_t byte = __shfl(tb, (int)(gbase + i), 64);
+        const uint32_t byte = (__shfl(tb, (int)(gbase + i / TB), 64) >> (8u * (i % TB))) & 0xffu;
         if (i < tail_len) r = table_step_byte(r, byte, ldsT8);
     }
     return r;
@@ -720,10 +814,12 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
 // bytes are fetched first, all at once, then walked with the reference's table step.
-__device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+__device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr_, uint32_t len, uint32_t state, bool on,
                                              const uint32_t* ldsT8) {
     uint32_t r = state;
     on = on && len != 0u;
+    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;  // see wave_crc
+    const GlobalByte ptr = (GlobalByte) reinterpret_cast<uint64_t>(ptr_);
     uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (on) {
 #pragma unroll
@@ -849,7 +945,9 @@ __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t
 //      reference (container.rs:48-60, :109-113): descriptor and header latency is
 //      paid once per W items, not once per item;
 //   B. the CRC spans, by length:  under 32 bytes    one lane each, 64 at a time
-//                                 32 .. 4080 bytes  one 16-lane group each, 4 at a time
+//                                 32 .. 4080 bytes  one 8-lane group each, 8 at a time (one
+//                                                   4-lane group, 16 at a time, while the
+//                                                   turn has none over 256 bytes)
 //                                 up to wave_max    the whole wave, one at a time
 //                                 longer            filed for the piece kernel
 //   C. lane j turns its item's registers into the verdict and stores it.
@@ -858,7 +956,12 @@ __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t
 // be filed with everything that follows its CRC check already decided.
 namespace {
 
-constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16 group tiles
+constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16 rounds of an 8-lane group
+#ifndef SIFT_GROUP4_MAX
+#define SIFT_GROUP4_MAX 256
+#endif
+constexpr uint32_t kGroup4Max = SIFT_GROUP4_MAX;  // widest span of a turn that runs on 4-lane groups
+static_assert(kGroup4Max <= 256, "4-lane groups take one round");
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
@@ -880,32 +983,40 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, ldsT8);
         if (tiny) res = r;
     }
-    // 32 .. 4080 bytes: a 16-lane group each, four at a time
-    unsigned long long m = __ballot(want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax);
-    while (m) {
-        int src[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            src[q] = m ? (int)__builtin_ctzll(m) : -1;
-            if (m) m &= m - 1;
-        }
-        const int q = (int)(lane >> 4);
-        const int mine = q == 0 ? src[0] : q == 1 ? src[1] : q == 2 ? src[2] : src[3];
-        const bool on = mine >= 0;
-        const uint64_t p = shfl64(sp, on ? mine : 0);
-        const uint32_t l = __shfl((uint32_t)sl, on ? mine : 0, 64);
-        const uint32_t r = group_crc(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t v = __shfl(r, 16 * k, 64);
-            if (src[k] >= 0 && (int)lane == src[k]) res = v;
+    // 32 .. 4080 bytes: a group of lanes each -- 4 lanes while no such span of the turn
+    // exceeds kGroup4Max bytes (16 spans per pass), else 8 (8 per pass)
+    const bool mid = want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax;
+    const unsigned long long m = __ballot(mid);
+    if (m) {
+        // the k-th span of the turn (in lane order) goes to group k: lane `rank` learns
+        // which lane holds it from a permutation that sends every lane id to its rank
+        // (spans first, in order; the other lanes behind them)
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        const uint32_t below = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const uint32_t rank = mid ? below : cnt + (lane - below);
+        const uint32_t holder = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)lane);
+        const bool narrow = !__any(mid && sl > (uint64_t)kGroup4Max);
+        const uint32_t per_pass = narrow ? 16u : 8u;
+        for (uint32_t first = 0; first < cnt; first += per_pass) {
+            const uint32_t idx = first + (narrow ? lane >> 2 : lane >> 3);
+            const bool on = idx < cnt;
+            const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
+            const uint64_t p = shfl64(sp, mine);
+            const uint32_t l = __shfl((uint32_t)sl, mine, 64);
+            const uint32_t r = narrow ? group_crc<4>(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX,
+                                                     ldsK, ldsT8, lane)
+                                      : group_crc<8>(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX,
+                                                     ldsK, ldsT8, lane);
+            // back to the lanes that hold the spans: rank - first is the group that did it
+            const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) * (narrow ? 4u : 8u)), 64);
+            if (mid && below >= first && below < first + per_pass) res = v;
         }
     }
     // longer: the whole wave, one at a time -- or filed for the piece kernel
-    m = __ballot(want && sl > (uint64_t)kGroupMax);
-    while (m) {
-        const int s = (int)__builtin_ctzll(m);
-        m &= m - 1;
+    unsigned long long ml = __ballot(want && sl > (uint64_t)kGroupMax);
+    while (ml) {
+        const int s = (int)__builtin_ctzll(ml);
+        ml &= ml - 1;
         const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, s));
         const uint64_t l = shfl64(sl, s);
         if (may_file && file_span(b, __shfl(item, s, 64), p, l, __shfl(cont, s, 64), __shfl(dlen, s, 64), lane)) {

@@ -200,6 +200,29 @@ def test_device_resident_descriptors(gpu, oracle):
     assert st.cpu().tolist() == [0, 0, 5, 0] and dl.cpu().tolist() == [0, 7, 0, 40000]
 
 
+@pytest.mark.parametrize("top", [31, 64, 65, 128, 129, 200, 256, 257, 400, 1024, 2048, 2049, 2100])
+def test_batch_short_items_every_group_width(gpu, top):
+    # a turn whose 32..4080-byte spans all fit 256 bytes runs on 4-lane groups, 16 spans a
+    # pass, any other on 8-lane groups, 8 a pass.  Lengths 0..top at every alignment, with
+    # counts that leave the last pass and the last turn ragged.
+    import zlib
+    rng = np.random.default_rng(1000 + top)
+    blob = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    M = 0xFFFFFFFF
+    for n in (1, 3, 17, 64, 100, 4099, 20000):
+        lens = [int(x) for x in rng.integers(0, top + 1, size=n)]
+        if n >= 17:
+            lens[5], lens[11] = top, max(top - 1, 0)
+        offs = [int(rng.integers(0, blob.size - k + 1)) for k in lens]
+        for state, xo in ((M, M), (0x9E3779B9, 0)):
+            got = gpu.compute_batch(state, d, offs, lens, xor_out=xo).cpu().numpy().view(np.uint32)
+            for i, (o, k) in enumerate(zip(offs, lens)):
+                want = (zlib.crc32(hb[o:o + k], state ^ M) ^ M) ^ xo
+                assert int(got[i]) == want, (n, i, o, k, hex(int(got[i])), hex(want))
+
+
 def test_batch_size_classes(gpu):
     # one wave / cut into 256 KiB pieces and stitched / whole-chip launch, in one batch
     import zlib

@@ -63,14 +63,16 @@ int main(int argc, char** argv) {
 
     // batch_bench chunk <bytes>: only Chunk::read on one chunk of that many data bytes (for rocprofv3)
     const bool only_items = argc >= 3 && !strcmp(argv[1], "items");  // batch_bench items <bytes>: one crc_batch size (for rocprofv3 --pmc)
+    const bool only_short = argc >= 2 && !strcmp(argv[1], "short");  // batch_bench short: items up to 64 KiB and the documents
     const bool only_chunk = (argc >= 3 && !strcmp(argv[1], "chunk")) || only_items;
     const size_t only_n = only_chunk ? strtoull(argv[2], nullptr, 0) : 0;
     printf("{\"rows\": [\n");
     bool first = true;
     // plain buffers back to back in the blob, descriptors in HBM and on the host
-    const size_t sizes[] = {64, 100, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
+    const size_t sizes[] = {64, 100, 128, 256, 512, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
     for (size_t size : sizes) {
         if (only_items ? size != only_n : only_chunk) continue;
+        if (only_short && size > 65536) continue;
         const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
         for (uint32_t i = 0; i < n; ++i) {
             off[i] = (uint64_t)i * size;
@@ -78,7 +80,7 @@ int main(int argc, char** argv) {
         }
         CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
-        for (int where = 0; where < (only_items ? 1 : 2); ++where) {
+        for (int where = 0; where < (only_items || only_short ? 1 : 2); ++where) {
             const uint64_t* po = where ? off.data() : d_off;
             const uint64_t* pl = where ? len.data() : d_len;
             for (int i = 0; i < 3; ++i)
@@ -104,9 +106,40 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    // Mixed lengths in one batch: every turn of a wave holds spans of very different sizes
+    for (size_t top : {(size_t)512, (size_t)4080}) {
+        if (only_chunk) break;
+        uint64_t x = 0x9E3779B97F4A7C15ull, pos = 0;
+        uint32_t n = 0;
+        while (n < (1u << 20)) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const uint64_t sz = 32 + (x >> 33) % (top - 31);
+            if (pos + sz > total) break;
+            off[n] = pos;
+            len[n] = sz;
+            pos += sz;
+            ++n;
+        }
+        CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
+        for (int i = 0; i < 3; ++i) SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, d_off, d_len, n, d_out, s));
+        CK(hipStreamSynchronize(s));
+        const int reps = 20;
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) SK(sift_crc32_batch_device(0, 0xFFFFFFFFu, 0xFFFFFFFFu, blob, d_off, d_len, n, d_out, s));
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%s {\"kind\": \"crc_batch_mixed\", \"descriptors\": \"device\", \"buffer_bytes\": \"32..%zu\", \"buffers\": %u, "
+               "\"device_us_per_call\": %.2f, \"GBps_device\": %.1f}",
+               first ? "" : ",\n", top, n, ms * 1e3 / reps, (double)pos / (ms * 1e-3 / reps) / 1e9);
+        first = false;
+        fflush(stdout);
+    }
     // Small batches: n buffers of 4 KiB (what a call costs when there is little to do)
     for (uint32_t n : {1u, 16u, 64u, 256u, 4096u}) {
-        if (only_chunk) break;
+        if (only_chunk || only_short) break;
         const size_t size = 4096;
         for (uint32_t i = 0; i < n; ++i) {
             off[i] = (uint64_t)i * size;
@@ -141,7 +174,7 @@ int main(int argc, char** argv) {
     }
     // Synchronous single calls through the C ABI (no Python in between): device-resident,
     // pageable host and pinned host input
-    if (!only_chunk) {
+    if (!only_chunk && !only_short) {
         std::vector<uint8_t> hbuf(1 << 20, 0x5A);
         uint8_t* pin = nullptr;
         CK(hipHostMalloc(reinterpret_cast<void**>(&pin), 1 << 20, hipHostMallocDefault));
@@ -172,7 +205,7 @@ int main(int argc, char** argv) {
     }
     // Chunk::read on ONE serialized chunk: length only in its header
     for (size_t n : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20, ((size_t)1 << 30) - 16}) {
-        if (only_chunk && n != only_n) continue;
+        if ((only_chunk && n != only_n) || only_short) continue;
         uint8_t hdr[8] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n, 'A', 'M', 'R', 'G'};
         CK(hipMemcpy(blob, hdr, 8, hipMemcpyHostToDevice));
         uint32_t crc = 0;
@@ -213,7 +246,8 @@ int main(int argc, char** argv) {
     // the shape of the reference's real data: one valid file built with the library's
     // own host entry point, repeated back to back
     if (!only_chunk) {
-        for (size_t payload : {(size_t)500, (size_t)2000, (size_t)8000}) {
+        for (size_t payload : {(size_t)100, (size_t)200, (size_t)500, (size_t)2000, (size_t)8000}) {
+            if (!only_short && payload < 500) continue;
             std::vector<uint8_t> pl(payload), file(payload + 33);
             for (size_t i = 0; i < payload; ++i) pl[i] = (uint8_t)(i * 131u + 7u);
             const int64_t flen = sift_write_document(0, pl.data(), payload, file.data(), file.size());
