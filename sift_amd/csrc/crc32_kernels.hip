@@ -584,8 +584,9 @@ __device__ __forceinline__ u32x4 fold_state_word(u32x4 w, int32_t vi, uint32_t h
 }
 
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
-                                             const uint32_t* ldsY, const uint32_t* ldsX, const uint32_t* ldsT8,
-                                             uint32_t lane, uint32_t lane32, uint32_t aw) {
+                                             const uint32_t* ldsY, const uint32_t* ldsG, const uint32_t* ldsX,
+                                             const uint32_t* ldsK, const uint32_t* ldsT8, uint32_t lane,
+                                             uint32_t lane32) {
     if (len < 32u) {
         uint32_t r = state;
         if (lane == 0)
@@ -653,8 +654,19 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
-    r = gf2_mulmod(r, aw);
-    r = wave_xor(r);
+    // the 64 lanes joined pairwise, as the lanes of a group are: at step j the lane whose
+    // bit j is clear holds the earlier 2^j vectors, multiplies by x^(128 * 2^j) and takes
+    // in its partner's.  Steps 0-3 look up the lane-join tables, step 4 the group path's
+    // x^(8*256) table, step 5 the same twice.  (Until round 2 every lane multiplied by its
+    // place, x^(128 * (63 - lane)), in 32 shift-and-xor steps: some 220 instructions a
+    // span against 90 here.  The time per span did not change -- this path waits for
+    // memory -- but the kernel needs 9-15 registers fewer and no longer spills.)
+    const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
+    r = mul_tab<kGroupReplLog2>(r, ldsG, l4) ^ __shfl_xor(r, 16, 64);
+    r = mul_tab<kGroupReplLog2>(mul_tab<kGroupReplLog2>(r, ldsG, l4), ldsG, l4) ^ __shfl_xor(r, 32, 64);
+    r = __shfl(r, 0, 64);
     // trailing bytes: every lane walks them alike (no divergence, no broadcast)
     for (uint32_t i = 0; i < tail_len; ++i) r = table_step_byte(r, __shfl(tb, (int)i, 64), ldsT8);
     return r;
@@ -685,14 +697,12 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     static_assert(GW == 8 || GW == 4, "group width");
     constexpr int LG = GW == 8 ? 3 : 2;                 // log2(GW): steps of the lane join
     constexpr int NCH = 16 / GW, LCH = 4 - LG;          // chains per lane
-    constexpr uint32_t TB = 16u / GW;                   // trailing bytes a lane fetches
     // A call passes generic pointers; say which memory they point into, or every
     // table lookup becomes a flat load that waits on both counters.
     typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
-    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
     const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
-    const uint32_t lg = lane & (uint32_t)(GW - 1), gbase = lane & (uint32_t)(64 - GW);
+    const uint32_t lg = lane & (uint32_t)(GW - 1);
     const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1), lx = lane & (uint32_t)(kXRepl - 1);  // table copies
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
@@ -701,12 +711,10 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     const GlobalVec vbase = (GlobalVec)(v0 << 4);
     const int32_t ntile = on ? (nvec + GW - 1) >> LG : 0;
     const uint32_t tail_len = on ? (uint32_t)((addr + len) & 15u) : 0u;
-    uint32_t tb = 0;
-    auto load_tail = [&]() {  // the group's trailing bytes, 16/GW a lane; issued behind the first vectors
-#pragma unroll
-        for (uint32_t k = 0; k < TB; ++k)
-            if (lg * TB + k < tail_len) tb |= (uint32_t)((GlobalByte)(v1 << 4))[lg * TB + k] << (8u * k);
-    };
+    // the < 16 bytes behind the last whole vector: every lane fetches the vector they lie
+    // in (one address per group), issued behind the first data vectors
+    u32x4 tw;
+    auto load_tail = [&]() { tw = vbase[tail_len ? nvec : 0]; };
     u32x4 acc = {0u, 0u, 0u, 0u};
     {
         // A round is one tile per chain; rounds are counted from the first (t = 0, the
@@ -805,9 +813,11 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     for (int j = 0; j < LG; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
     // meaningful register, the others walk along
-    for (uint32_t i = 0; __any(i < tail_len); ++i) {
-        const uint32_t byte = (__shfl(tb, (int)(gbase + i / TB), 64) >> (8u * (i % TB))) & 0xffu;
-        if (i < tail_len) r = table_step_byte(r, byte, ldsT8);
+#pragma unroll
+    for (uint32_t i = 0; i < 15u; ++i) {
+        if (!__any(i < tail_len)) break;
+        const uint32_t step = table_step_byte(r, (tw[i >> 2] >> (8u * (i & 3u))) & 0xffu, ldsT8);
+        r = i < tail_len ? step : r;
     }
     return r;
 }
@@ -975,7 +985,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
                                           uint32_t item, uint32_t cont, uint32_t dlen, bool may_file,
                                           uint32_t& res, bool& filed, const uint32_t* ldsY,
                                           const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
-                                          const uint32_t* ldsT8, uint32_t lane, uint32_t lane32, uint32_t aw) {
+                                          const uint32_t* ldsT8, uint32_t lane, uint32_t lane32) {
     const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
     // under 32 bytes: a lane each
     const bool tiny = want && sl <= (uint64_t)kTinyMax;
@@ -1023,7 +1033,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             if ((int)lane == s) filed = true;
             continue;
         }
-        const uint32_t r = wave_crc(p, l, state, ldsY, ldsX, ldsT8, lane, lane32, aw);
+        const uint32_t r = wave_crc(p, l, state, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32);
         if ((int)lane == s) res = r;
     }
 }
@@ -1052,7 +1062,6 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     for (int i = tid; i < kXrWords; i += kThreads) ldsX[i] = b.tabs->X[i >> kXReplLog2];
     for (int i = tid; i < kKWords; i += kThreads) ldsK[i] = (&b.tabs->K[0][0])[i];
     for (int i = tid; i < kT8Words; i += kThreads) ldsT8[i] = b.tabs->T8[i];
-    const uint32_t aw = b.tabs->Kt[kThreads - 64 + lane];  // x^(128 * (63 - lane))
     __syncthreads();
 
     const uint32_t W = b.items_per_wave;
@@ -1134,7 +1143,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 }
             }
             crc_spans<MODE>(b, slot ? span1 : span0, reinterpret_cast<uint64_t>(sp), sl, i, cont, dlen, may_file,
-                            r, f, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32, aw);
+                            r, f, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32);
             if (slot) {
                 r1 = r;
             } else {
