@@ -583,6 +583,21 @@ __device__ __forceinline__ u32x4 fold_state_word(u32x4 w, int32_t vi, uint32_t h
     return w;
 }
 
+// The 16 bytes of v moved up by d (0..15) byte positions, zeros behind them.
+__device__ __forceinline__ u32x4 shl_bytes(u32x4 v, uint32_t d) {
+    const uint32_t down = 32u - 8u * (d & 3u), q = d >> 2;  // a 64-bit shift by 32 is allowed: d & 3 == 0
+    u32x4 t;
+    t[0] = (uint32_t)(((uint64_t)v[0] << 32) >> down);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) t[c] = (uint32_t)((((uint64_t)v[c] << 32) | v[c - 1]) >> down);
+    u32x4 o;
+    o[0] = q == 0 ? t[0] : 0u;
+    o[1] = q == 0 ? t[1] : q == 1 ? t[0] : 0u;
+    o[2] = q == 0 ? t[2] : q == 1 ? t[1] : q == 2 ? t[0] : 0u;
+    o[3] = q == 0 ? t[3] : q == 1 ? t[2] : q == 2 ? t[1] : t[0];
+    return o;
+}
+
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
                                              const uint32_t* ldsY, const uint32_t* ldsG, const uint32_t* ldsX,
                                              const uint32_t* ldsK, const uint32_t* ldsT8, uint32_t lane,
@@ -690,7 +705,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
 // wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few instructions
 // per pass -- but the kernel around it can only keep what the callee leaves of the 128
 // registers, which is why the rounds below are written to stay near 50.
-template <int GW>
+template <int GW, bool ENDF>
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
                                               const uint32_t* ldsG_, const uint32_t* ldsX_,
                                               const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
@@ -700,21 +715,37 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     // A call passes generic pointers; say which memory they point into, or every
     // table lookup becomes a flat load that waits on both counters.
     typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
+    typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+    typedef __attribute__((address_space(1))) const u32x4_u* GlobalVecU;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
     const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
     const uint32_t lg = lane & (uint32_t)(GW - 1);
     const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1), lx = lane & (uint32_t)(kXRepl - 1);  // table copies
+    // Two framings.  ENDF: the span is framed from its END: vector v covers the 16 bytes
+    // that end 16 * (nvec - 1 - v) bytes before the span's end, whatever their address (the
+    // hardware takes 16-byte loads at any byte address; off a 4-byte boundary they stream
+    // at 5.1 instead of 6.5 TB/s).  Nothing trails the last vector -- no byte-at-a-time
+    // tail, 8 instructions a byte for every lane of the wave, as many bytes as the longest
+    // tail of the pass -- and vector 0 is the short one: it begins `lead` bytes before the
+    // span does.  Those bytes are not read (they may lie before the start of an
+    // allocation): vector 0 is read AT the span's first byte and moved up instead.
+    // Otherwise: vectors are the aligned 16-byte blocks of memory; vector 0 has `lead`
+    // bytes of something else in front, masked off, and up to 15 bytes trail the last one.
+    // The first wins while spans are short (a mix of 32..512-byte spans at all alignments:
+    // 15 % faster), the second when the loads matter more than the tail (a mix of
+    // 32..4080: 5 % slower framed from the end, 2 KB documents 10 %).
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
-    const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
-    const int32_t nvec = (int32_t)(v1 - v0);  // 2..255
-    const uint32_t h = (uint32_t)(addr & 15u);
-    const GlobalVec vbase = (GlobalVec)(v0 << 4);
+    const int32_t nvec = ENDF ? (int32_t)((len + 15u) >> 4) : (int32_t)(((addr + len) >> 4) - (addr >> 4));  // 2..255
+    const uint32_t lead = ENDF ? (uint32_t)nvec * 16u - len : (uint32_t)(addr & 15u);                        // 0..15
+    const uint32_t tail_len = ENDF || !on ? 0u : (uint32_t)((addr + len) & 15u);
     const int32_t ntile = on ? (nvec + GW - 1) >> LG : 0;
-    const uint32_t tail_len = on ? (uint32_t)((addr + len) & 15u) : 0u;
+    auto vec = [&](int32_t vi) {  // vector vi > 0; anything else reads vector 0 (ENDF: the span's first 16 bytes)
+        if constexpr (ENDF) return (GlobalVecU)(addr + (uint64_t)(uint32_t)(vi > 0 ? 16 * vi - (int32_t)lead : 0));
+        else return (GlobalVec)(((addr >> 4) + (uint64_t)(uint32_t)(vi > 0 ? vi : 0)) << 4);
+    };
     // the < 16 bytes behind the last whole vector: every lane fetches the vector they lie
     // in (one address per group), issued behind the first data vectors
-    u32x4 tw;
-    auto load_tail = [&]() { tw = vbase[tail_len ? nvec : 0]; };
+    u32x4 tw = {0u, 0u, 0u, 0u};
     u32x4 acc = {0u, 0u, 0u, 0u};
     {
         // A round is one tile per chain; rounds are counted from the first (t = 0, the
@@ -731,15 +762,14 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         const int32_t nround = GW == 4 ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
         const int32_t tile0 = NCH * (nround - 1);
         const int32_t vi0 = nvec - GW * (tile0 + 1) + (int32_t)lg;  // round 0, chain c: vector vi0 - GW * c
-        // Vectors 0 and 1 need the head mask and the state bytes.  A lane holds at most
-        // one of them: in round 0, chain vi0 >> LG (its vector there is vi0 mod GW), or --
-        // when vector 0 is alone in its tile -- vector 1 in round 1, last chain.
+        // Vector 0 needs moving up (or its head masking) and vectors 0 and 1 the state bytes
+        // (at bytes lead .. lead + 3 of the two).  A lane holds at most one of them: in round 0, chain vi0 >> LG (its
+        // vector there is vi0 mod GW), or -- when vector 0 is alone in its tile -- vector 1
+        // in round 1, last chain.
         const bool head0 = on && vi0 >= 0 && (vi0 & (GW - 1)) <= 1;
         const bool head1 = GW != 4 && on && vi0 == 1 - GW;
         const int32_t hvi = head1 ? 1 : (vi0 & (GW - 1)), hc = vi0 >> LG;
-        const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
-        const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, h, state);
-        const u32x4 keep = hvi == 0 ? mask_head(ones, h) : ones;
+        const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, lead, state);
         u32x4 ch[NCH];
         {
             bool ex[NCH];
@@ -747,18 +777,29 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
             for (int c = 0; c < NCH; ++c) {
                 const int32_t vi = vi0 - GW * c;
                 ex[c] = on && tile0 + c < ntile && vi >= 0;
-                ch[c] = vbase[ex[c] ? vi : 0];
+                ch[c] = *vec(ex[c] ? vi : 0);
             }
-            load_tail();
+            if constexpr (!ENDF) tw = *vec(tail_len ? nvec : 0);
             __builtin_amdgcn_sched_barrier(0);
+            u32x4 hw = {0u, 0u, 0u, 0u};  // the lane's vector 0 or 1, if it has one
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const bool hd = head0 && hc == c;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t x = ex[c] ? ch[c][k] : 0u;
-                    ch[c][k] = hd ? (x & keep[k]) ^ delta[k] : x;
+                    ch[c][k] = ex[c] ? ch[c][k] : 0u;
+                    hw[k] = hd ? ch[c][k] : hw[k];
                 }
+            }
+            const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+            const u32x4 up = ENDF ? shl_bytes(hw, lead) : hw & mask_head(ones, lead);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hw[k] = (hvi == 0 ? up[k] : hw[k]) ^ delta[k];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bool hd = head0 && hc == c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ch[c][k] = hd ? hw[k] : ch[c][k];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -767,10 +808,10 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
             const int32_t vt = vi0 + 16 * t;  // chain c: vector vt - GW * c
             u32x4 w[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(vbase + (ha ? vt - GW * c : 0));
+            for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(vec(ha ? vt - GW * c : 0));
             __builtin_amdgcn_sched_barrier(0);
             if (t == 1 && __any(head1)) {  // worked out again here: four registers fewer across the loop
-                const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, h, state);
+                const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, lead, state);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[NCH - 1][k] ^= head1 ? d1[k] : 0u;
             }
@@ -802,7 +843,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     // the lane's four words, then the GW lanes joined pairwise: at step j the
     // lane whose bit j is clear holds the earlier 2^j vectors, multiplies by
     // x^(128 * 2^j) (four lookups in K[j]) and takes in its partner's.  Lane 0 of the
-    // group ends up with the body's register.  (A 32-step register multiply by the
+    // group ends up with the span's register.  (A 32-step register multiply by the
     // lane's place, x^(128 * (GW - 1 - lane)), costs 7 instructions a bit; this path is
     // VALU-bound -- a wave64 instruction takes four cycles -- so lookups win.  Four
     // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
@@ -813,11 +854,13 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
     for (int j = 0; j < LG; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
     // meaningful register, the others walk along
+    if constexpr (!ENDF) {
 #pragma unroll
-    for (uint32_t i = 0; i < 15u; ++i) {
-        if (!__any(i < tail_len)) break;
-        const uint32_t step = table_step_byte(r, (tw[i >> 2] >> (8u * (i & 3u))) & 0xffu, ldsT8);
-        r = i < tail_len ? step : r;
+        for (uint32_t i = 0; i < 15u; ++i) {
+            if (!__any(i < tail_len)) break;
+            const uint32_t step = table_step_byte(r, (tw[i >> 2] >> (8u * (i & 3u))) & 0xffu, ldsT8);
+            r = i < tail_len ? step : r;
+        }
     }
     return r;
 }
@@ -970,8 +1013,13 @@ constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16
 #ifndef SIFT_GROUP4_MAX
 #define SIFT_GROUP4_MAX 256
 #endif
+#ifndef SIFT_END_FRAMED_MAX
+#define SIFT_END_FRAMED_MAX 1024
+#endif
 constexpr uint32_t kGroup4Max = SIFT_GROUP4_MAX;  // widest span of a turn that runs on 4-lane groups
 static_assert(kGroup4Max <= 256, "4-lane groups take one round");
+constexpr uint32_t kEndFramedMax = SIFT_END_FRAMED_MAX;  // ... that is framed from the spans' ends
+static_assert(kEndFramedMax >= kGroup4Max, "4-lane groups are framed from the end");
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
@@ -1006,17 +1054,17 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t rank = mid ? below : cnt + (lane - below);
         const uint32_t holder = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)lane);
         const bool narrow = !__any(mid && sl > (uint64_t)kGroup4Max);
+        const bool endf = !__any(mid && sl > (uint64_t)kEndFramedMax);  // see group_crc
         const uint32_t per_pass = narrow ? 16u : 8u;
         for (uint32_t first = 0; first < cnt; first += per_pass) {
             const uint32_t idx = first + (narrow ? lane >> 2 : lane >> 3);
             const bool on = idx < cnt;
             const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
-            const uint64_t p = shfl64(sp, mine);
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
             const uint32_t l = __shfl((uint32_t)sl, mine, 64);
-            const uint32_t r = narrow ? group_crc<4>(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX,
-                                                     ldsK, ldsT8, lane)
-                                      : group_crc<8>(reinterpret_cast<const uint8_t*>(p), l, state, on, ldsG, ldsX,
-                                                     ldsK, ldsT8, lane);
+            const uint32_t r = narrow ? group_crc<4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane)
+                               : endf ? group_crc<8, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane)
+                                      : group_crc<8, false>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             // back to the lanes that hold the spans: rank - first is the group that did it
             const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) * (narrow ? 4u : 8u)), 64);
             if (mid && below >= first && below < first + per_pass) res = v;

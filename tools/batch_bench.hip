@@ -286,6 +286,55 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    // the same on files of MIXED sizes packed back to back (every alignment, every tail):
+    // 256 distinct valid files with payloads of 40..top bytes, repeated
+    for (size_t top : {(size_t)500, (size_t)4000}) {
+        if (only_chunk) break;
+        std::vector<std::vector<uint8_t>> kinds(256);
+        uint64_t x = 0x2545F4914F6CDD1Dull;
+        for (auto& f : kinds) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const size_t payload = 40 + (x >> 33) % (top - 39);
+            std::vector<uint8_t> pl(payload);
+            for (size_t i = 0; i < payload; ++i) pl[i] = (uint8_t)(i * 131u + (x >> 20));
+            f.resize(payload + 33);
+            if (sift_write_document(0, pl.data(), payload, f.data(), f.size()) != (int64_t)f.size()) return 5;
+        }
+        std::vector<uint8_t> host;
+        host.reserve(total);
+        uint32_t n = 0;
+        while (n < (1u << 20)) {
+            const auto& f = kinds[(n * 2654435761u) >> 24];
+            if (host.size() + f.size() > total) break;
+            off[n] = host.size();
+            len[n] = f.size();
+            host.insert(host.end(), f.begin(), f.end());
+            ++n;
+        }
+        CK(hipMemcpy(blob, host.data(), host.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_off, off.data(), 8ull * n, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_len, len.data(), 8ull * n, hipMemcpyHostToDevice));
+        for (int i = 0; i < 3; ++i) SK(sift_read_documents_device(0, blob, d_off, d_len, n, d_out, nullptr, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<uint32_t> st(n);
+        CK(hipMemcpy(st.data(), d_out, 4ull * n, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i)
+            if (st[i] != 0) {
+                fprintf(stderr, "mixed document %u: status %u\n", i, st[i]);
+                return 6;
+            }
+        const int reps = 20;
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) SK(sift_read_documents_device(0, blob, d_off, d_len, n, d_out, nullptr, s));
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf(",\n {\"kind\": \"read_documents_mixed\", \"descriptors\": \"device\", \"file_bytes\": \"73..%zu\", \"files\": %u, "
+               "\"device_us_per_call\": %.2f, \"Mfiles_per_s\": %.1f, \"GBps_device\": %.1f}",
+               top + 33, n, ms * 1e3 / reps, n / (ms * 1e-3 / reps) / 1e6, (double)host.size() / (ms * 1e-3 / reps) / 1e9);
+        fflush(stdout);
+    }
     printf("\n]}\n");
     return 0;
 }
