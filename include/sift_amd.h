@@ -208,7 +208,7 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  * byte length): both device arrays (used in place), or host arrays (pinned ones
  * are read in place by the GPU, pageable ones are copied to the device first).
  * Short items are taken 64 at a time by a wave (one lane per item for parsing,
- * checks and the verdict; the CRC itself by one lane, a 16-lane group or the
+ * checks and the verdict; the CRC itself by one lane, a group of 4 or 8 lanes or the
  * whole wave, by length).  An item whose CRC span is long
  * (over 256 KiB when n >= 4096, over 32 KiB otherwise) is cut ON THE DEVICE --
  * in the chunk modes the length is only in the chunk's header -- into pieces of
