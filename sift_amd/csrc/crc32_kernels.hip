@@ -705,13 +705,14 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
 // wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few instructions
 // per pass -- but the kernel around it can only keep what the callee leaves of the 128
 // registers, which is why the rounds below are written to stay near 50.
-template <int GW, bool ENDF>
+template <int GW, int NCH, bool ENDF>
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
                                               const uint32_t* ldsG_, const uint32_t* ldsX_,
                                               const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
-    static_assert(GW == 8 || GW == 4, "group width");
-    constexpr int LG = GW == 8 ? 3 : 2;                 // log2(GW): steps of the lane join
-    constexpr int NCH = 16 / GW, LCH = 4 - LG;          // chains per lane
+    static_assert((GW == 8 && NCH == 2) || (GW == 4 && (NCH == 4 || NCH == 2)) || (GW == 2 && NCH == 2), "group shape");
+    constexpr int LG = GW == 8 ? 3 : GW == 4 ? 2 : 1;   // log2(GW): steps of the lane join
+    constexpr int LCH = NCH == 4 ? 2 : 1;               // log2(chains per lane)
+    constexpr bool ONE_ROUND = GW < 8;                  // the span is at most GW * NCH vectors
     // A call passes generic pointers; say which memory they point into, or every
     // table lookup becomes a flat load that waits on both counters.
     typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
@@ -759,7 +760,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         // compiler they took 70-100 registers, and a callee that big makes the kernel
         // around it spill.  4-lane groups only take spans of one round (kGroup4Max <= 256
         // bytes: at most 16 vectors at any alignment).
-        const int32_t nround = GW == 4 ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
+        const int32_t nround = ONE_ROUND ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
         const int32_t tile0 = NCH * (nround - 1);
         const int32_t vi0 = nvec - GW * (tile0 + 1) + (int32_t)lg;  // round 0, chain c: vector vi0 - GW * c
         // Vector 0 needs moving up (or its head masking) and vectors 0 and 1 the state bytes
@@ -767,7 +768,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         // vector there is vi0 mod GW), or -- when vector 0 is alone in its tile -- vector 1
         // in round 1, last chain.
         const bool head0 = on && vi0 >= 0 && (vi0 & (GW - 1)) <= 1;
-        const bool head1 = GW != 4 && on && vi0 == 1 - GW;
+        const bool head1 = !ONE_ROUND && on && vi0 == 1 - GW;
         const int32_t hvi = head1 ? 1 : (vi0 & (GW - 1)), hc = vi0 >> LG;
         const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, lead, state);
         u32x4 ch[NCH];
@@ -803,7 +804,7 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int32_t t = 1; GW != 4 && __any(t < nround); ++t) {
+        for (int32_t t = 1; !ONE_ROUND && __any(t < nround); ++t) {
             const bool ha = t < nround;
             const int32_t vt = vi0 + 16 * t;  // chain c: vector vt - GW * c
             u32x4 w[NCH];
@@ -1017,12 +1018,22 @@ constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16
 #define SIFT_END_FRAMED_MAX 1024
 #endif
 constexpr uint32_t kGroup4Max = SIFT_GROUP4_MAX;  // widest span of a turn that runs on 4-lane groups
-static_assert(kGroup4Max <= 256, "4-lane groups take one round");
+static_assert(kGroup4Max >= 128 && kGroup4Max <= 256, "4-lane groups take one round of 2 or 4 chains");
 constexpr uint32_t kEndFramedMax = SIFT_END_FRAMED_MAX;  // ... that is framed from the spans' ends
 static_assert(kEndFramedMax >= kGroup4Max, "4-lane groups are framed from the end");
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
+}
+
+// The largest v of the wave, in every lane.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
 }
 
 // The spans `slot` of this wave's items: registers over the whole span into `res`
@@ -1041,8 +1052,8 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, ldsT8);
         if (tiny) res = r;
     }
-    // 32 .. 4080 bytes: a group of lanes each -- 4 lanes while no such span of the turn
-    // exceeds kGroup4Max bytes (16 spans per pass), else 8 (8 per pass)
+    // 32 .. 4080 bytes: a group of lanes each -- 2 lanes while no such span of the turn
+    // exceeds 64 bytes (32 spans per pass), 4 up to kGroup4Max (16 per pass), else 8 (8 per pass)
     const bool mid = want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax;
     const unsigned long long m = __ballot(mid);
     if (m) {
@@ -1053,20 +1064,24 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t below = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
         const uint32_t rank = mid ? below : cnt + (lane - below);
         const uint32_t holder = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)lane);
-        const bool narrow = !__any(mid && sl > (uint64_t)kGroup4Max);
-        const bool endf = !__any(mid && sl > (uint64_t)kEndFramedMax);  // see group_crc
-        const uint32_t per_pass = narrow ? 16u : 8u;
+        // the group's shape follows the longest span of the turn (see group_crc)
+        const uint32_t longest = wave_max_u32(mid ? (uint32_t)sl : 0u);
+        const uint32_t lgw = longest <= 64u ? 1u : longest <= (uint32_t)kGroup4Max ? 2u : 3u;  // log2(lanes per group)
+        const uint32_t per_pass = 64u >> lgw;
         for (uint32_t first = 0; first < cnt; first += per_pass) {
-            const uint32_t idx = first + (narrow ? lane >> 2 : lane >> 3);
+            const uint32_t idx = first + (lane >> lgw);
             const bool on = idx < cnt;
             const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
             const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
             const uint32_t l = __shfl((uint32_t)sl, mine, 64);
-            const uint32_t r = narrow ? group_crc<4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane)
-                               : endf ? group_crc<8, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane)
-                                      : group_crc<8, false>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            uint32_t r;
+            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            else r = group_crc<8, 2, false>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             // back to the lanes that hold the spans: rank - first is the group that did it
-            const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) * (narrow ? 4u : 8u)), 64);
+            const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) << lgw), 64);
             if (mid && below >= first && below < first + per_pass) res = v;
         }
     }
