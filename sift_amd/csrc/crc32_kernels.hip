@@ -598,16 +598,38 @@ __device__ __forceinline__ u32x4 shl_bytes(u32x4 v, uint32_t d) {
     return o;
 }
 
+// The first two tiles and the trailing bytes of a span the whole wave will take, requested
+// ahead of time: every load unconditional (what the span does not have is read at vector 0
+// and dropped later), so that they stay in flight across whatever comes next.
+struct WaveHead {
+    u32x4 t0, t1;
+    uint32_t tb;
+};
+__device__ __forceinline__ void wave_request(const uint8_t* ptr, uint64_t len, uint32_t lane, WaveHead& hd) {
+    typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
+    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
+    const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
+    const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
+    const int64_t nvec = (int64_t)(v1 - v0);
+    const GlobalVec vbase = (GlobalVec)(v0 << 4);
+    const int64_t ntile = (nvec + 63) >> 6;
+    const int64_t vi = nvec - ntile * 64 + (int64_t)lane;
+    const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
+    hd.t0 = vbase[vi >= 0 ? vi : 0];
+    hd.t1 = vbase[ntile > 1 ? vi + 64 : 0];
+    hd.tb = ((GlobalByte)((tail_len ? v1 : v0) << 4))[lane < tail_len ? lane : 0u];
+}
+
+// CRC of a span of more than kGroupMax bytes by the whole wave.  `hd` holds the span's
+// first tiles (wave_request); the NEXT span the wave will take (np, nl; this one again if
+// there is none) is requested into `nxt` before this span's lanes are joined: the join
+// is a chain of dependent lookups and shuffles with nothing in flight, and the next
+// span's first tile used to be asked for only behind it -- two idle stretches per span.
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
                                              const uint32_t* ldsY, const uint32_t* ldsG, const uint32_t* ldsX,
                                              const uint32_t* ldsK, const uint32_t* ldsT8, uint32_t lane,
-                                             uint32_t lane32) {
-    if (len < 32u) {
-        uint32_t r = state;
-        if (lane == 0)
-            for (uint32_t i = 0; i < (uint32_t)len; ++i) r = crc_step_byte(r, ptr[i]);
-        return __shfl(r, 0, 64);
-    }
+                                             uint32_t lane32, const WaveHead& hd, const uint8_t* np, uint64_t nl,
+                                             WaveHead& nxt) {
     const uint32_t lw = lane32 & (uint32_t)(kWaveRepl - 1), lx = lane32 & (uint32_t)(kXRepl - 1);  // table copies
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
@@ -617,7 +639,6 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // or the loads below are flat loads, which count as LDS traffic too -- every wait for
     // a table lookup then waits for the data in flight as well.
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
-    typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;
     const GlobalVec vbase = (GlobalVec)(v0 << 4);
     const int64_t ntile = (nvec + 63) >> 6;
     int64_t vi = nvec - ntile * 64 + (int64_t)lane;  // tiles aligned to the end of the body
@@ -625,13 +646,12 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // Tile 0 may start before vector 0 (front padding, head mask).  The four
     // state bytes land in vectors 0 and 1, which are in tile 0 or, when tile 0
     // holds vector 0 alone, in tiles 0 and 1: both are peeled.
-    u32x4 acc = {0u, 0u, 0u, 0u};
-    if (vi >= 0) acc = vbase[vi];
-    // the < 16 bytes behind the last whole vector: lane k fetches byte k now, beside
-    // the data, instead of one lane fetching them after everything else
+    u32x4 acc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = vi >= 0 ? hd.t0[c] : 0u;
+    // the < 16 bytes behind the last whole vector: lane k fetched byte k beside the data
     const uint32_t tail_len = (uint32_t)((addr + len) & 15u);
-    uint32_t tb = 0;
-    if (lane < tail_len) tb = ((GlobalByte)(v1 << 4))[lane];
+    const uint32_t tb = lane < tail_len ? hd.tb : 0u;
     if (vi >= 0) {
         if (vi == 0 && h) acc = mask_head(acc, h);
         acc = fold_state(acc, vi, h, state);
@@ -640,7 +660,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     int64_t left = ntile - 1;
     GlobalVec p = vbase + vi;
     if (left > 0) {
-        const u32x4 w = fold_state(*p, vi, h, state);
+        const u32x4 w = fold_state(hd.t1, vi, h, state);
         horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
         p += 64;
         --left;
@@ -666,6 +686,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
         const u32x4 w = __builtin_nontemporal_load(p);
         horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
     }
+    wave_request(np, nl, lane, nxt);
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
@@ -1087,16 +1108,27 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
     }
     // longer: the whole wave, one at a time -- or filed for the piece kernel
     unsigned long long ml = __ballot(want && sl > (uint64_t)kGroupMax);
+    WaveHead hd;
+    int requested = -1;  // the lane whose span `hd` was requested for
     while (ml) {
         const int s = (int)__builtin_ctzll(ml);
         ml &= ml - 1;
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, s));
-        const uint64_t l = shfl64(sl, s);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(uniform64(shfl64(sp, s)));
+        const uint64_t l = uniform64(shfl64(sl, s));
         if (may_file && file_span(b, __shfl(item, s, 64), p, l, __shfl(cont, s, 64), __shfl(dlen, s, 64), lane)) {
             if ((int)lane == s) filed = true;
             continue;
         }
-        const uint32_t r = wave_crc(p, l, state, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32);
+        if (requested != s) wave_request(p, l, lane, hd);
+        // the span behind this one (it may yet be filed: its two tiles are then dropped);
+        // behind the last one, this span's last 64 bytes (just read: no new traffic)
+        const int ns = ml ? (int)__builtin_ctzll(ml) : -1;
+        const uint8_t* np = ns >= 0 ? reinterpret_cast<const uint8_t*>(uniform64(shfl64(sp, ns))) : p + (l - 64u);
+        const uint64_t nl = ns >= 0 ? uniform64(shfl64(sl, ns)) : 64u;
+        WaveHead nxt;
+        const uint32_t r = wave_crc(p, l, state, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32, hd, np, nl, nxt);
+        hd = nxt;
+        requested = ns;
         if ((int)lane == s) res = r;
     }
 }
