@@ -70,7 +70,7 @@ struct DeviceTables {
     uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
-    uint32_t Y256[4 * 256];  // Y256[k*256+b] = (b << 8k) * x^(8*256) mod P  (16-lane group tiles, batch kernel)
+    uint32_t Y256[4 * 256];  // Y256[k*256+b] = (b << 8k) * x^(8*256) mod P  (a chain of a lane group steps over 16 vectors, batch kernel)
     uint32_t T8[256];        // T8[b] = b * x^8 mod P: the reference's CRC_TABLE itself (crc.rs:2-20), for
                              // bytes that are walked one at a time (tails, spans under 32 bytes)
     uint32_t K[4][4 * 256];  // K[j][k*256+b] = (b << 8k) * x^(128 * 2^j): joins neighbouring lanes' residues

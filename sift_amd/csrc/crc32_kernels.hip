@@ -708,24 +708,26 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     return r;
 }
 
-// CRC of a span of 32 .. kGroupMax bytes by ONE GROUP OF GW LANES (8 or 4), 64/GW spans
-// per wave at a time: the wave kernel's algebra at group scale.  The body is cut into
+// CRC of a span of 32 .. kGroupMax bytes by ONE GROUP OF GW LANES (8, 4 or 2), 64/GW spans
+// per wave at a time: the wave kernel's algebra at group scale.  The span is cut into
 // tiles of GW vectors, aligned to its end so that only the first can be partial; lane l
-// of the group takes vector l of every tile.  A lane keeps 16/GW accumulators ("chains"):
-// the tiles, counted from the end, go to the chains round-robin, so that whatever GW is,
-// a chain steps over 16 vectors and every Horner step multiplies by x^(8*256) from the one
-// kGroupRepl-copy table (mul_tab / horner_tab on ldsG).  At the end a lane's chains are
-// joined with x^(128*GW) (the lane-join table of the same constant), then the lanes.
-// The work per byte is the same for every GW; what a narrow group saves is the work per
-// PASS (the x^32 fold, the lane join, the trailing bytes, the call), which 8 or 16 spans
-// share, and the lanes left idle by a span shorter than a tile.  (Round 2 began with
-// 16-lane groups, four spans a pass: 64-byte items 3.3x slower, 1 KiB items 15 %, mixed
-// 32..4080-byte items 5 %; nothing was faster.)  Every lane of the wave calls this; `on`
-// says whether the lane's group has a span.  The register over the whole span comes back
-// in lane 0 of the group.  Not inlined: inside the batch kernel's item loop, beside the
-// wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few instructions
-// per pass -- but the kernel around it can only keep what the callee leaves of the 128
-// registers, which is why the rounds below are written to stay near 50.
+// of the group takes vector l of every tile.  A lane keeps NCH accumulators ("chains"):
+// the tiles, counted from the end, go to the chains round-robin.  An 8-lane group has
+// two, so a chain steps over 16 vectors and every Horner step multiplies by x^(8*256)
+// from the one kGroupRepl-copy table (mul_tab on ldsG), as a 16-lane group with one chain
+// would; the 4- and 2-lane shapes only take spans that fit their chains (4 x 4, 4 x 2
+// and 2 x 2 vectors: 256, 128 and 64 bytes) and have no Horner loop at all.  At the end
+// a lane's chains are joined with x^(128*GW) (the lane-join table of that constant), then
+// the lanes.  The work per byte is the same for every shape; what a narrow group saves
+// is the work per PASS (the x^32 fold, the lane join, the head, the call), which 8, 16
+// or 32 spans share, and the lanes left idle by a span shorter than a tile.  (Round 2
+// began with 16-lane groups, four spans a pass: 64-byte items 4.4x slower, 1 KiB items
+// 15 %, mixed 32..4080-byte items 5 %; nothing was faster.)  Every lane of the wave calls
+// this; `on` says whether the lane's group has a span.  The register over the whole span
+// comes back in lane 0 of the group.  Not inlined: inside the batch kernel's item loop,
+// beside the wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few
+// instructions per pass -- but the kernel around it can only keep what the callee
+// leaves of the 128 registers, which is why the rounds below are written to stay near 50.
 template <int GW, int NCH, bool ENDF>
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
                                               const uint32_t* ldsG_, const uint32_t* ldsX_,
@@ -1020,9 +1022,9 @@ __device__ __forceinline__ uint32_t read_chunk_head(const uint8_t* ptr, uint64_t
 //      reference (container.rs:48-60, :109-113): descriptor and header latency is
 //      paid once per W items, not once per item;
 //   B. the CRC spans, by length:  under 32 bytes    one lane each, 64 at a time
-//                                 32 .. 4080 bytes  one 8-lane group each, 8 at a time (one
-//                                                   4-lane group, 16 at a time, while the
-//                                                   turn has none over 256 bytes)
+//                                 32 .. 4080 bytes  one group of lanes each, by the turn's
+//                                                   longest: 2 lanes up to 64 bytes (32 at
+//                                                   a time), 4 up to 256 (16), else 8 (8)
 //                                 up to wave_max    the whole wave, one at a time
 //                                 longer            filed for the piece kernel
 //   C. lane j turns its item's registers into the verdict and stores it.
