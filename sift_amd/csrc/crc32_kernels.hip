@@ -729,9 +729,9 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
 // instructions per pass -- but the kernel around it can only keep what the callee
 // leaves of the 128 registers, which is why the rounds below are written to stay near 50.
 template <int GW, int NCH, bool ENDF>
-__device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
-                                              const uint32_t* ldsG_, const uint32_t* ldsX_,
-                                              const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
+__device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+                                                   const uint32_t* ldsG_, const uint32_t* ldsX_,
+                                                   const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
     static_assert((GW == 8 && NCH == 2) || (GW == 4 && (NCH == 4 || NCH == 2)) || (GW == 2 && NCH == 2), "group shape");
     constexpr int LG = GW == 8 ? 3 : GW == 4 ? 2 : 1;   // log2(GW): steps of the lane join
     constexpr int LCH = NCH == 4 ? 2 : 1;               // log2(chains per lane)
@@ -887,6 +887,13 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
         }
     }
     return r;
+}
+
+template <int GW, int NCH, bool ENDF>
+__device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+                                              const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
+                                              const uint32_t* ldsT8, uint32_t lane) {
+    return group_crc_body<GW, NCH, ENDF>(ptr, len, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
 }
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
@@ -1098,7 +1105,9 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
             const uint32_t l = __shfl((uint32_t)sl, mine, 64);
             uint32_t r;
-            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
+            // inlined as well makes the document mode spill)
+            if (longest <= 64u) r = group_crc_body<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
