@@ -200,11 +200,13 @@ def test_device_resident_descriptors(gpu, oracle):
     assert st.cpu().tolist() == [0, 0, 5, 0] and dl.cpu().tolist() == [0, 7, 0, 40000]
 
 
-@pytest.mark.parametrize("top", [31, 64, 65, 128, 129, 200, 256, 257, 400, 1024, 2048, 2049, 2100])
+@pytest.mark.parametrize("top", [31, 64, 65, 128, 129, 200, 256, 257, 400, 1024, 1025, 2049, 4080, 4081])
 def test_batch_short_items_every_group_width(gpu, top):
-    # a turn whose 32..4080-byte spans all fit 256 bytes runs on 4-lane groups, 16 spans a
-    # pass, any other on 8-lane groups, 8 a pass.  Lengths 0..top at every alignment, with
-    # counts that leave the last pass and the last turn ragged.
+    # the group's shape follows the longest 32..4080-byte span of a turn (2 lanes up to 64
+    # bytes, 4 x 2 vectors up to 128, 4 x 4 up to 256, 8 lanes beyond), its framing too
+    # (from the spans' ends up to 1 KiB, memory's 16-byte blocks beyond).  Lengths 0..top at
+    # every alignment, with counts that leave the last pass and the last turn ragged; one
+    # span starts at the first byte of the allocation and one ends at its last.
     import zlib
     rng = np.random.default_rng(1000 + top)
     blob = rng.integers(0, 256, size=1 << 20, dtype=np.uint8)
@@ -216,6 +218,8 @@ def test_batch_short_items_every_group_width(gpu, top):
         if n >= 17:
             lens[5], lens[11] = top, max(top - 1, 0)
         offs = [int(rng.integers(0, blob.size - k + 1)) for k in lens]
+        if n >= 3:
+            offs[0], offs[1] = 0, blob.size - lens[1]
         for state, xo in ((M, M), (0x9E3779B9, 0)):
             got = gpu.compute_batch(state, d, offs, lens, xor_out=xo).cpu().numpy().view(np.uint32)
             for i, (o, k) in enumerate(zip(offs, lens)):
