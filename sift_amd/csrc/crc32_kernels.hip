@@ -1284,13 +1284,23 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 uint8_t* slot = const_cast<uint8_t*>(chunk) + 8ull + dlen;
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
-            } else if (crc != be32(chunk + 8ull + dlen)) {
-                status = 5;  // container.rs:60-63
-            } else if (MODE == 2) {
-                if (be32(chunk + 4) != 0x414D5247u) status = 1;  // expect_type(AMRG)
-                else if (st2) status = st2;                      // read_chunk on the SEND chunk, before its crc
-                else if ((r1 ^ 0xFFFFFFFFu) != be32(send + 8ull + d2)) status = 5;
-                else if (be32(send + 4) != 0x53454E44u) status = 1;  // expect_type(SEND)
+            } else if (MODE == 1) {
+                if (crc != be32(chunk + 8ull + dlen)) status = 5;  // container.rs:60-63
+            } else {
+                // everything the checks below look at is requested at once: read where
+                // each check stands, behind the branch of the one before, they were up
+                // to four trips to memory one after the other
+                const uint32_t stored0 = be32(chunk + 8ull + dlen), type0 = be32(chunk + 4);
+                uint32_t stored2 = 0, type2c = 0;
+                if (st2 == 0) {
+                    stored2 = be32(send + 8ull + d2);
+                    type2c = be32(send + 4);
+                }
+                if (crc != stored0) status = 5;                             // container.rs:60-63
+                else if (type0 != 0x414D5247u) status = 1;                  // expect_type(AMRG)
+                else if (st2) status = st2;                                 // read_chunk on the SEND chunk, before its crc
+                else if ((r1 ^ 0xFFFFFFFFu) != stored2) status = 5;
+                else if (type2c != 0x53454E44u) status = 1;                 // expect_type(SEND)
             }
         }
         b.out[i] = status;
