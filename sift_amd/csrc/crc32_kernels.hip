@@ -728,10 +728,50 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
 // beside the wave path, it pushed the kernel past 128 VGPRs; as a call it costs a few
 // instructions per pass -- but the kernel around it can only keep what the callee
 // leaves of the 128 registers, which is why the rounds below are written to stay near 50.
+// The first round's vectors of a group's span (and, in the aligned framing, the vector its
+// trailing bytes lie in): what group_crc_body loads first, as a request of its own, so that
+// two passes' loads can be in flight before the first pass waits (group_crc_pair).  Same
+// geometry and the same unconditional loads as in group_crc_body.
+template <int NCH>
+struct GroupLoads {
+    u32x4 ch[NCH];
+    u32x4 tw;
+};
+template <int GW, int NCH, bool ENDF>
+__device__ __forceinline__ void group_request(const uint8_t* ptr, uint32_t len, bool on, uint32_t lane,
+                                              GroupLoads<NCH>& g) {
+    constexpr int LG = GW == 8 ? 3 : GW == 4 ? 2 : 1;
+    constexpr int LCH = NCH == 4 ? 2 : 1;
+    constexpr bool ONE_ROUND = GW < 8;
+    typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+    typedef __attribute__((address_space(1))) const u32x4_u* GlobalVecU;
+    typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
+    const uint32_t lg = lane & (uint32_t)(GW - 1);
+    const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
+    const int32_t nvec = ENDF ? (int32_t)((len + 15u) >> 4) : (int32_t)(((addr + len) >> 4) - (addr >> 4));
+    const uint32_t lead = ENDF ? (uint32_t)nvec * 16u - len : (uint32_t)(addr & 15u);
+    const uint32_t tail_len = ENDF || !on ? 0u : (uint32_t)((addr + len) & 15u);
+    const int32_t ntile = on ? (nvec + GW - 1) >> LG : 0;
+    auto vec = [&](int32_t vi) {
+        if constexpr (ENDF) return (GlobalVecU)(addr + (uint64_t)(uint32_t)(vi > 0 ? 16 * vi - (int32_t)lead : 0));
+        else return (GlobalVec)(((addr >> 4) + (uint64_t)(uint32_t)(vi > 0 ? vi : 0)) << 4);
+    };
+    const int32_t nround = ONE_ROUND ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
+    const int32_t tile0 = NCH * (nround - 1);
+    const int32_t vi0 = nvec - GW * (tile0 + 1) + (int32_t)lg;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int32_t vi = vi0 - GW * c;
+        g.ch[c] = *vec(on && tile0 + c < ntile && vi >= 0 ? vi : 0);
+    }
+    if constexpr (!ENDF) g.tw = *vec(tail_len ? nvec : 0);
+}
+
 template <int GW, int NCH, bool ENDF>
 __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
                                                    const uint32_t* ldsG_, const uint32_t* ldsX_,
-                                                   const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane) {
+                                                   const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane,
+                                                   const GroupLoads<NCH>* pre = nullptr) {
     static_assert((GW == 8 && NCH == 2) || (GW == 4 && (NCH == 4 || NCH == 2)) || (GW == 2 && NCH == 2), "group shape");
     constexpr int LG = GW == 8 ? 3 : GW == 4 ? 2 : 1;   // log2(GW): steps of the lane join
     constexpr int LCH = NCH == 4 ? 2 : 1;               // log2(chains per lane)
@@ -801,9 +841,9 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
             for (int c = 0; c < NCH; ++c) {
                 const int32_t vi = vi0 - GW * c;
                 ex[c] = on && tile0 + c < ntile && vi >= 0;
-                ch[c] = *vec(ex[c] ? vi : 0);
+                ch[c] = pre ? pre->ch[c] : *vec(ex[c] ? vi : 0);
             }
-            if constexpr (!ENDF) tw = *vec(tail_len ? nvec : 0);
+            if constexpr (!ENDF) tw = pre ? pre->tw : *vec(tail_len ? nvec : 0);
             __builtin_amdgcn_sched_barrier(0);
             u32x4 hw = {0u, 0u, 0u, 0u};  // the lane's vector 0 or 1, if it has one
 #pragma unroll
@@ -894,6 +934,32 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
                                               const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
                                               const uint32_t* ldsT8, uint32_t lane) {
     return group_crc_body<GW, NCH, ENDF>(ptr, len, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+}
+
+// Two passes in one: both spans' vectors are requested before the first is worked on, so a
+// turn makes half as many dependent trips to memory (and half as many calls).  Results in
+// the low (a) and high (b) word.
+template <int GW, int NCH, bool ENDF>
+__device__ __forceinline__ uint64_t group_crc_pair_body(const uint8_t* pa, uint32_t la, bool ona, const uint8_t* pb,
+                                                        uint32_t lb, bool onb, uint32_t state, const uint32_t* ldsG,
+                                                        const uint32_t* ldsX, const uint32_t* ldsK,
+                                                        const uint32_t* ldsT8, uint32_t lane) {
+    GroupLoads<NCH> ga, gb;
+    group_request<GW, NCH, ENDF>(pa, la, ona, lane, ga);
+    group_request<GW, NCH, ENDF>(pb, lb, onb, lane, gb);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t ra = group_crc_body<GW, NCH, ENDF>(pa, la, state, ona, ldsG, ldsX, ldsK, ldsT8, lane, &ga);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t rb = group_crc_body<GW, NCH, ENDF>(pb, lb, state, onb, ldsG, ldsX, ldsK, ldsT8, lane, &gb);
+    return ((uint64_t)rb << 32) | ra;
+}
+template <int GW, int NCH, bool ENDF>
+__device__ __attribute__((noinline)) uint64_t group_crc_pair(const uint8_t* pa, uint32_t la, bool ona,
+                                                             const uint8_t* pb, uint32_t lb, bool onb, uint32_t state,
+                                                             const uint32_t* ldsG, const uint32_t* ldsX,
+                                                             const uint32_t* ldsK, const uint32_t* ldsT8,
+                                                             uint32_t lane) {
+    return group_crc_pair_body<GW, NCH, ENDF>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane);
 }
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
@@ -1098,16 +1164,35 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t longest = wave_max_u32(mid ? (uint32_t)sl : 0u);
         const uint32_t lgw = longest <= 64u ? 1u : longest <= (uint32_t)kGroup4Max ? 2u : 3u;  // log2(lanes per group)
         const uint32_t per_pass = 64u >> lgw;
-        for (uint32_t first = 0; first < cnt; first += per_pass) {
+        uint32_t first = 0;
+        // the two smallest shapes take two passes at a time while there are two to take
+        // (not in the document mode: it has no registers for that)
+        for (; MODE != 2 && longest <= 128u && first + per_pass < cnt; first += 2u * per_pass) {
+            const uint32_t ia = first + (lane >> lgw), ib = ia + per_pass;
+            const bool ona = ia < cnt, onb = ib < cnt;
+            const int ma = (int)__shfl(holder, (int)(ona ? ia : 0u), 64), mb = (int)__shfl(holder, (int)(onb ? ib : 0u), 64);
+            const uint8_t* pa = reinterpret_cast<const uint8_t*>(shfl64(sp, ma));
+            const uint8_t* pb = reinterpret_cast<const uint8_t*>(shfl64(sp, mb));
+            const uint32_t la = __shfl((uint32_t)sl, ma, 64), lb = __shfl((uint32_t)sl, mb, 64);
+            // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
+            // inlined as well makes the document mode spill)
+            const uint64_t rr = longest <= 64u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG,
+                                                                                  ldsX, ldsK, ldsT8, lane)
+                                               : group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX,
+                                                                            ldsK, ldsT8, lane);
+            const uint32_t k = below - first;  // which of the 2 * per_pass spans, for the lanes it concerns
+            const int src = (int)((k & (per_pass - 1u)) << lgw);
+            const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
+            if (mid && below >= first && k < 2u * per_pass) res = k < per_pass ? va : vb;
+        }
+        for (; first < cnt; first += per_pass) {
             const uint32_t idx = first + (lane >> lgw);
             const bool on = idx < cnt;
             const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
             const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
             const uint32_t l = __shfl((uint32_t)sl, mine, 64);
             uint32_t r;
-            // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
-            // inlined as well makes the document mode spill)
-            if (longest <= 64u) r = group_crc_body<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
             else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
