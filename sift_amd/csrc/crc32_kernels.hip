@@ -867,28 +867,45 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int32_t t = 1; !ONE_ROUND && __any(t < nround); ++t) {
-            const bool ha = t < nround;
-            const int32_t vt = vi0 + 16 * t;  // chain c: vector vt - GW * c
+        // Rounds 1 .. : round t + 1's vectors are requested before round t is stepped (a
+        // round read and then stepped is a trip to memory per 256 bytes of span with
+        // nothing else in flight for the group).
+        // (Only while some group of the pass has a round to ask for: with two-round spans
+        // alone -- 0.5 KB documents -- the idle requests cost 12 %.)
+        if (!ONE_ROUND && __any(nround > 1)) {
             u32x4 w[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(vec(ha ? vt - GW * c : 0));
-            __builtin_amdgcn_sched_barrier(0);
-            if (t == 1 && __any(head1)) {  // worked out again here: four registers fewer across the loop
-                const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, lead, state);
+            for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(vec(nround > 1 ? vi0 + 16 - GW * c : 0));
+            for (int32_t t = 1; __any(t < nround); ++t) {
+                const bool ha = t < nround;
+                const int32_t vn = vi0 + 16 * (t + 1);  // next round, chain c: vector vn - GW * c
+                u32x4 wn[NCH];
+                if (__any(t + 1 < nround)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w[NCH - 1][k] ^= head1 ? d1[k] : 0u;
-            }
+                    for (int c = 0; c < NCH; ++c) wn[c] = __builtin_nontemporal_load(vec(t + 1 < nround ? vn - GW * c : 0));
+                } else {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (ha) {  // two words at a time: half the lookups in flight, half the registers
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 2; k < 4; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                    for (int c = 0; c < NCH; ++c) wn[c] = u32x4{0u, 0u, 0u, 0u};
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (t == 1 && __any(head1)) {  // worked out again here: four registers fewer across the loop
+                    const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, lead, state);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[NCH - 1][k] ^= head1 ? d1[k] : 0u;
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (ha) {  // two words at a time: half the lookups in flight, half the registers
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 2; k < 4; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) w[c] = wn[c];
             }
         }
         // the lane's chains: chain c is GW vectors (x^(128*GW), lane-join table LG) ahead
