@@ -1182,10 +1182,10 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t lgw = longest <= 64u ? 1u : longest <= (uint32_t)kGroup4Max ? 2u : 3u;  // log2(lanes per group)
         const uint32_t per_pass = 64u >> lgw;
         uint32_t first = 0;
-        // the two smallest shapes take two passes at a time while there are two to take
-        // (not in the document mode: it has no registers for that)
-        for (; MODE != 2 && (longest <= 128u || (MODE == 0 && longest > (uint32_t)kGroup4Max && longest <= (uint32_t)kEndFramedMax)) &&
-               first + per_pass < cnt;
+        // two passes at a time while there are two to take
+        // (plain buffers: every end-framed shape; chunk modes: up to 128 bytes, larger pairs
+        // make them spill; the document mode: none, it has no registers for that)
+        for (; MODE != 2 && (longest <= 128u || (MODE == 0 && longest <= (uint32_t)kEndFramedMax)) && first + per_pass < cnt;
              first += 2u * per_pass) {
             const uint32_t ia = first + (lane >> lgw), ib = ia + per_pass;
             const bool ona = ia < cnt, onb = ib < cnt;
@@ -1199,8 +1199,9 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
                                                                                   ldsX, ldsK, ldsT8, lane)
                                 : longest <= 128u ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX,
                                                                                ldsK, ldsT8, lane)
-                                                  : group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX,
-                                                                               ldsK, ldsT8, lane);
+                                : longest <= (uint32_t)kGroup4Max
+                                    ? group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane)
+                                    : group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane);
             const uint32_t k = below - first;  // which of the 2 * per_pass spans, for the lanes it concerns
             const int src = (int)((k & (per_pass - 1u)) << lgw);
             const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
