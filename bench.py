@@ -13,7 +13,8 @@ rank r owns range r, and the job ends with one all-gather of every step's
 no data-path collective.
 
 Prints one JSON line (rank 0).  `roofline` is for the tile kernel, timed with
-HIP events on its own stream during the timed steps; `cpu_baseline` is the C
+HIP events on its own stream during the timed steps (the event pair rides on the
+kernel's dispatch, see sift_profile_begin in include/sift_amd.h); `cpu_baseline` is the C
 port of the reference's byte-at-a-time loop (oracle/sift_oracle.c), 1 core, on
 a bounded sample.
 """
@@ -264,6 +265,10 @@ def main() -> None:
                 "kernel_us_max": round(ks[-1], 2) if ks else None,
                 "launches_timed": kl.value,
                 "event_stride": stride,
+                "timing": ("HIP event pair recorded before and behind each timed launch (SIFT_PROF_EXT=0)"
+                           if os.environ.get("SIFT_PROF_EXT") == "0" else
+                           "HIP event pair attached to each timed launch's dispatch (hipExtLaunchKernelGGL): "
+                           "the dispatch's own start/end timestamps, what rocprofv3 reports"),
                 "algorithmic_bytes_per_launch": n,
                 "traffic": load_traffic(workload),
             },

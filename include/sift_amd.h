@@ -74,10 +74,14 @@ size_t sift_crc32_workspace_bytes(void);
 
 /* ------------------------------------------------------------ measurement
  * No reference counterpart.  Between _begin and _end every `stride`-th
- * sift_crc32_compute_* / sift_chunk_crc_device launch on `device` brackets its
+ * sift_crc32_compute_* / sift_chunk_crc_device launch on `device` times its
  * tile kernel (the dominant kernel) with a HIP event pair on the launch's own
- * stream, up to `max_launches` bracketed launches.  (An event pair costs a few
- * microseconds of idle GPU around the kernel, hence the stride.)  _end waits
+ * stream, up to `max_launches` timed launches.  The pair is attached to the
+ * kernel's dispatch (hipExtLaunchKernelGGL: the events take the dispatch's start
+ * and end timestamps, the quantity rocprofv3 reports); with SIFT_PROF_EXT=0 in
+ * the environment the events are recorded before and behind the launch instead
+ * (round 1's method: 2-3 us of marker packets inside the bracket and a few
+ * microseconds of idle stream around it, hence the stride).  _end waits
  * for them and returns the summed kernel time in milliseconds and the number
  * of launches measured.
  * bench.py divides algorithmic bytes by this for `roofline.achieved`. */

@@ -497,10 +497,19 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
             ++c->prof_used;
         }
     }
-    if (ev0) SIFT_HIP(hipEventRecord(ev0, stream));
-    launch_tiles(t, f, m, (int)groups, tpg > 1, stream);
+    // Measurement (sift_profile_begin/_end): the event pair rides on the tile kernel's own
+    // dispatch (hipExtLaunchKernelGGL: its start and end timestamps) -- what rocprofv3
+    // reports for the launch -- instead of two marker packets around it, which put 2-3 us
+    // of their own between the events and ~8 us of idle stream around every timed launch.
+    // SIFT_PROF_EXT=0 brings the markers back.
+    static const bool ext_events = [] {
+        const char* e = getenv("SIFT_PROF_EXT");
+        return !(e && *e == '0');
+    }();
+    if (ev0 && !ext_events) SIFT_HIP(hipEventRecord(ev0, stream));
+    launch_tiles(t, f, m, (int)groups, tpg > 1, stream, ext_events ? ev0 : nullptr, ext_events ? ev1 : nullptr);
     SIFT_HIP(hipGetLastError());
-    if (ev1) SIFT_HIP(hipEventRecord(ev1, stream));
+    if (ev1 && !ext_events) SIFT_HIP(hipEventRecord(ev1, stream));
     if (groups > 1 && !t.single_launch) {
         launch_combine(workspace, f, m, stream);
         SIFT_HIP(hipGetLastError());

@@ -20,6 +20,7 @@
 // crc32_combine_kernel inputs under 32 bytes (one lane), and the second launch
 //     of the two-launch A/B form (tree over the <= 1024 residues).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -1869,8 +1870,18 @@ void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* 
 }
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
-                  bool use_y, void* stream) {
+                  bool use_y, void* stream, void* ev_start, void* ev_stop) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ev_start && ev_stop) {
+        // measurement: the two events take the start and end timestamps of this very
+        // dispatch (no marker packets before and behind it on the stream)
+        hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
+        if (use_y)
+            hipExtLaunchKernelGGL(crc32_tiles_kernel<true>, dim3(groups), dim3(kThreads), 0, s, e0, e1, 0, t, f, m);
+        else
+            hipExtLaunchKernelGGL(crc32_tiles_kernel<false>, dim3(groups), dim3(kThreads), 0, s, e0, e1, 0, t, f, m);
+        return;
+    }
     if (use_y)
         hipLaunchKernelGGL(crc32_tiles_kernel<true>, dim3(groups), dim3(kThreads), 0, s, t, f, m);
     else

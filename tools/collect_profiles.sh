@@ -8,10 +8,11 @@ R=$PWD
 RND=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -rf gpurun_out/${RND}_trace gpurun_out/${RND}_pmc_fetch gpurun_out/${RND}_pmc_write gpurun_out/${RND}_pmc_sq gpurun_out/${RND}_batch_trace
+rm -rf gpurun_out/${RND}_trace gpurun_out/${RND}_trace20 gpurun_out/${RND}_pmc_fetch gpurun_out/${RND}_pmc_write gpurun_out/${RND}_pmc_sq gpurun_out/${RND}_batch_trace
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${RND}.json
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_trace -- python3 $R/bench.py --no-cpu-baseline --no-secondary > $R/gpurun_out/${RND}_trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_trace20 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/${RND}_trace20.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${RND}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $R/gpurun_out/${RND}_pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${RND}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $R/gpurun_out/${RND}_pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/${RND}_pmc_sq -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $R/gpurun_out/${RND}_pmc_sq.log 2>&1

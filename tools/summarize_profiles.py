@@ -85,6 +85,22 @@ with open(one(f"{rnd}_trace/*/*kernel_trace.csv")) as f:
 durs.sort()
 trimmed = durs[: max(1, len(durs) * 99 // 100)]  # without the slowest 1 %
 
+# the same command as the committed bench line (--steps 20 --warmup 5) under the profiler:
+# its LAST 20 launches are the timed steps, the ones bench.py's own events time
+steps20 = None
+hits20 = glob.glob(os.path.join(GO, f"{rnd}_trace20/*/*kernel_trace.csv"))
+if hits20:
+    rows20 = []
+    with open(hits20[0]) as f:
+        for r in csv.DictReader(f):
+            if KERNEL in r["Kernel_Name"] and "true" in r["Kernel_Name"]:
+                rows20.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    rows20.sort()
+    last = sorted(d for _, d in rows20[-20:])
+    if last:
+        steps20 = {"launches_in_trace": len(rows20), "timed_launches": len(last), "avg_us": sum(last) / len(last),
+                   "median_us": last[len(last) // 2], "min_us": last[0], "max_us": last[-1]}
+
 vec = alg / 1024.0  # wave-level 1 KiB loads per launch
 summary = {
     "round": rnd,
@@ -99,6 +115,7 @@ summary = {
         "avg_us_without_slowest_1pct": sum(trimmed) / len(trimmed) if durs else None,
         "launches_over_1ms": sum(1 for d in durs if d > 1000.0),
     },
+    "rocprof_kernel_trace_steps20_timed_launches": steps20,
     "pmc_per_launch": pmc,
     "derived": {
         "valu_wave_instr_per_1KiB_wave_load": pmc["SQ_INSTS_VALU"]["mean_per_launch"] / vec,
@@ -114,6 +131,7 @@ summary = {
 with open(os.path.join(PR, f"{rnd}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary["rocprof_kernel_trace"], indent=1))
+print(json.dumps(steps20, indent=1))
 print(json.dumps(summary["derived"], indent=1))
 print(json.dumps(traffic, indent=1))
 
