@@ -42,7 +42,9 @@ enum {
     /* errors the reference cannot have (it never leaves the CPU) */
     SIFT_ERR_NO_DEVICE = 16,               /* no HIP device / device index out of range */
     SIFT_ERR_HIP = 17,                     /* a HIP runtime call failed */
-    SIFT_ERR_INVALID_ARG = 18              /* NULL pointer with non-zero length, etc. */
+    SIFT_ERR_INVALID_ARG = 18,             /* NULL pointer with non-zero length, etc. */
+    SIFT_ERR_TOO_MANY_THREADS = 19         /* more than 1024 threads alive that have used the synchronous
+                                              entry points (each keeps a pinned result slot until it exits) */
 };
 
 /* Human-readable text for a status code (static storage). */
@@ -66,10 +68,23 @@ void sift_shutdown(void);
  * half-way can leave it otherwise, and this puts it right.  No reference
  * counterpart. */
 int sift_reset_workspace(int device);
+/* Gives back everything the library keeps for `stream` on `device` (its 12 KiB
+ * workspace block, its batch scratch, its pinned descriptor buffers and events),
+ * after waiting for the stream.  Call it before hipStreamDestroy on a stream that
+ * was passed to this library with workspace = NULL or to a batch entry point;
+ * without it those blocks stay until sift_shutdown, and a later stream that
+ * happens to get the same handle value inherits them (harmless: they are zero
+ * between calls).  For hipStreamPerThread it releases the calling thread's entry.
+ * A stream the library holds nothing for is not an error.  No reference
+ * counterpart. */
+int sift_release_stream(int device, void *stream);
 /* Bytes of device workspace one in-flight sift_crc32_compute_device call
  * needs when the caller brings its own (see `workspace` below).  A caller's
- * workspace must be zero-filled once before its first use; the library leaves
- * it reusable (its arrival counter back at zero) after every call. */
+ * workspace must be 256-byte aligned (as hipMalloc returns it: the exchange words
+ * are 8-byte atomics on 128-byte lines of their own; a misaligned pointer is
+ * refused with SIFT_ERR_INVALID_ARG) and zero-filled once before its first use;
+ * the library leaves it reusable (its arrival counter back at zero) after every
+ * call. */
 size_t sift_crc32_workspace_bytes(void);
 
 /* ------------------------------------------------------------ measurement
@@ -91,6 +106,13 @@ int sift_profile_end(int device, double *tile_kernel_ms, int *launches);
  * into `samples_ms` (may be NULL). */
 int sift_profile_end_samples(int device, double *tile_kernel_ms, int *launches, float *samples_ms,
                              int max_samples);
+/* Same for every kernel of the library: between _begin and _end the batch entry
+ * points time their kernels as well (every launch, whatever `stride`; each timed
+ * launch takes one of the `max_launches` pairs).  kernel_ms[k] / launches[k]:
+ * k = 0 the tile kernel, 1 the batch (wave) kernel, 2 the piece kernel.
+ * `tile_samples_ms` as samples_ms above. */
+int sift_profile_end_kernels(int device, double kernel_ms[3], int launches[3], float *tile_samples_ms,
+                             int max_samples);
 
 /* Measurement knobs, process-wide.  No reference counterpart. */
 enum {
@@ -102,8 +124,9 @@ enum {
     SIFT_TUNE_BATCH_WAVE_MAX = 3,/* bytes of CRC span one wave keeps before the item is cut;
                                     0 (default) = 256 KiB for n >= 4096 items, else 32 KiB */
     SIFT_TUNE_BATCH_PIECE_LOG2 = 4, /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
-    SIFT_TUNE_HOST_COPY_THREADS = 6, /* host threads (incl. the caller's) that fill the pinned bounce
-                                    ring for pageable input of more than 512 KiB, 1..16 (default 4);
+    SIFT_TUNE_HOST_COPY_THREADS = 6, /* helper threads that fill the pinned bounce ring for pageable
+                                    input of more than 512 KiB, 1..16 (default 4; the calling thread
+                                    copies nothing, it launches the kernel over the slot filled before);
                                     0: always the staged hipMemcpyAsync path.  Set before the first
                                     host-input call on a device. */
     SIFT_TUNE_BATCH_PLAN = 5     /* 1 (default): up to 64 items (not whole documents) go straight to the
@@ -124,7 +147,10 @@ int sift_tune(int key, int value);
  * the library then uses the workspace it keeps for `stream` (one per stream,
  * allocated and zeroed on that stream's first call, so that first call
  * allocates; calls on one stream run in order and share it safely, calls on
- * different streams never share one, however many are in flight).  Under HIP
+ * different streams never share one, however many are in flight;
+ * hipStreamPerThread, one handle value that names a different stream in every
+ * thread, is keyed by the calling thread as well; NULL and hipStreamLegacy are one
+ * stream; sift_release_stream gives a stream's block back).  Under HIP
  * graph capture a NULL workspace is refused (SIFT_ERR_INVALID_ARG): a graph may
  * replay on any stream, so bring a workspace, or use
  * sift_crc32_compute_device_static.
@@ -138,7 +164,7 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t *d_stat
  * IN THE REFERENCE (it never leaves the CPU).  Like sift_crc32_compute_device with
  * workspace = NULL, except that the workspace is an 8.3 KiB array in the
  * library's own static device memory (one copy per GPU, held until the process
- * ends) instead of a slot of the allocated ring, and that the call itself makes
+ * ends) instead of the block allocated for the stream, and that the call itself makes
  * no hipMalloc / hipFree or any other allocating call.  Requirements:
  *  - sift_init(device) has returned SIFT_OK earlier (set-up allocates the
  *    constant tables; this call does not, and returns SIFT_ERR_INVALID_ARG if the
@@ -209,8 +235,12 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  * The data-parallel form of the two functions above, for callers that hold
  * many independent buffers / serialized chunks in HBM (bulk load of many
  * files).  `offsets` / `lens` are arrays of n entries (byte offset from `d_base`,
- * byte length): both device arrays (used in place), or host arrays (pinned ones
- * are read in place by the GPU, pageable ones are copied to the device first).
+ * byte length): both device arrays (used in place), or host arrays.  Host arrays of
+ * up to 1 MiB together (64 K items) are copied before the call returns, pinned or
+ * not: the caller may refill or free them at once.  Larger pageable arrays are
+ * copied as well (stream-ordered); larger PINNED arrays (hipHostMalloc /
+ * hipHostRegister) are read in place by the GPU and must stay unchanged until
+ * `stream` has passed the call.
  * Short items are taken 64 at a time by a wave (one lane per item for parsing,
  * checks and the verdict; the CRC itself by one lane, a group of 4 or 8 lanes or the
  * whole wave, by length).  An item whose CRC span is long

@@ -23,6 +23,7 @@ ERR_READ_CRC_MISMATCH = 5
 ERR_NO_DEVICE = 16
 ERR_HIP = 17
 ERR_INVALID_ARG = 18
+ERR_TOO_MANY_THREADS = 19
 
 TUNE_SINGLE_LAUNCH = 1
 TUNE_BATCH_CUT = 2
@@ -38,8 +39,8 @@ STATIC_MAX_LEN = 1 << 38
 
 # every symbol include/sift_amd.h declares; tests check the .so exports them all
 EXPORTS = (
-    "sift_strerror", "sift_last_error", "sift_init", "sift_shutdown", "sift_reset_workspace",
-    "sift_profile_end_samples",
+    "sift_strerror", "sift_last_error", "sift_init", "sift_shutdown", "sift_reset_workspace", "sift_release_stream",
+    "sift_profile_end_samples", "sift_profile_end_kernels",
     "sift_profile_begin", "sift_profile_end", "sift_tune", "sift_crc32_workspace_bytes", "sift_crc32_compute_device",
     "sift_crc32_compute_device_static", "sift_crc32_compute_device_sync", "sift_crc32_compute_host",
     "sift_digest_new", "sift_digest_update", "sift_digest_update_device",
@@ -77,8 +78,12 @@ def _load() -> C.CDLL:
     L.sift_shutdown.argtypes = []
     L.sift_reset_workspace.restype = i32
     L.sift_reset_workspace.argtypes = [i32]
+    L.sift_release_stream.restype = i32
+    L.sift_release_stream.argtypes = [i32, vp]
     L.sift_profile_end_samples.restype = i32
     L.sift_profile_end_samples.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_float), i32]
+    L.sift_profile_end_kernels.restype = i32
+    L.sift_profile_end_kernels.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_float), i32]
     L.sift_profile_begin.restype = i32
     L.sift_profile_begin.argtypes = [i32, i32, i32]
     L.sift_profile_end.restype = i32

@@ -1,5 +1,5 @@
 // crc32_api.hip -- host side of the C ABI declared in include/sift_amd.h:
-// per-device context (tables, scratch ring, staging), launch geometry, and
+// per-device context (tables, per-stream scratch, staging), launch geometry, and
 // the Digest / compute entry points (reference: sift-persist/src/crc.rs).
 #include <hip/hip_runtime.h>
 
@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <thread>
 #include <string>
 #include <unordered_map>
@@ -166,7 +167,8 @@ class CopyCrew {
 // call, kept until sift_shutdown).  Nothing is handed out round-robin: there is
 // no state that a call still in flight on another stream could be sharing.
 struct StreamScratch {
-    uint32_t* compute_ws = nullptr;  // kSlotWords, zero between calls (sift_crc32_compute_* with workspace NULL)
+    std::mutex m;                    // one call at a time issues its launch sequence on this stream's scratch
+    std::atomic<uint32_t*> compute_ws{nullptr};  // kStreamBlockBytes, zero between calls (sift_crc32_compute_* with workspace NULL)
     uint8_t* batch = nullptr;        // batch entry points: counters | records | piece list; counters zero between calls
     size_t batch_bytes = 0;
     // Pageable host descriptors of up to kDescStageBytes per call are copied by the
@@ -191,13 +193,41 @@ constexpr size_t kDescStageBytes = 1u << 20;
 constexpr size_t kDescSmallBytes = 64u << 10;
 constexpr unsigned kDescSmallSlots = 16;
 
+// What a stream's scratch is filed under.  A hipStream_t names one stream -- except
+// hipStreamPerThread, ONE handle value that names a different stream in every thread:
+// calls made with it are keyed by (handle, calling thread), or two threads would run
+// concurrently on one exchange block.  NULL and hipStreamLegacy are the same stream.
+struct StreamKey {
+    hipStream_t stream = nullptr;
+    uint64_t thread = 0;  // 0 unless stream == hipStreamPerThread
+    bool operator==(const StreamKey& o) const { return stream == o.stream && thread == o.thread; }
+};
+struct StreamKeyHash {
+    size_t operator()(const StreamKey& k) const {
+        return std::hash<void*>()(static_cast<void*>(k.stream)) ^ (size_t)(k.thread * 0x9E3779B97F4A7C15ull);
+    }
+};
+uint64_t this_thread_id() {
+    static std::atomic<uint64_t> next{1};
+    thread_local const uint64_t id = next.fetch_add(1);
+    return id;
+}
+StreamKey key_of(hipStream_t s) {
+    if (s == hipStreamPerThread) return StreamKey{s, this_thread_id()};
+    if (s == hipStreamLegacy) return StreamKey{nullptr, 0};
+    return StreamKey{s, 0};
+}
+// Bumped whenever an entry leaves any per_stream map (sift_release_stream,
+// sift_shutdown): invalidates the threads' one-entry lookup caches.
+std::atomic<uint64_t> g_scratch_epoch{1};
+
 struct DeviceCtx {
     int device = -1;
     int groups_max = 0;  // workgroups per launch = CUs (one 132 KiB-LDS workgroup per CU)
     DeviceTables* d_tabs = nullptr;
     uint32_t* static_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
-    std::mutex scratch_mutex;            // guards per_stream, and a batch call's launch sequence
-    std::unordered_map<hipStream_t, StreamScratch> per_stream;
+    std::mutex scratch_mutex;            // guards the per_stream map only (entries have their own mutex)
+    std::unordered_map<StreamKey, std::unique_ptr<StreamScratch>, StreamKeyHash> per_stream;
     // host-input staging (sift_crc32_compute_host)
     bool staging_ready = false;
     uint8_t* d_stage[2] = {nullptr, nullptr};
@@ -216,22 +246,30 @@ struct DeviceCtx {
     hipEvent_t bounce_read[kBounceSlots] = {};
     CopyCrew* crew = nullptr;
     std::mutex host_path_mutex;
-    struct MatsEntry {
-        int64_t tpg = -1;
-        int groups = -1;
-        CombineMats m;
-    };
-    std::array<MatsEntry, 8> mats_cache;
-    unsigned mats_next = 0;
-    std::mutex mats_mutex;
     // measurement support (sift_profile_begin / _end): event pairs around the
     // tile kernel of each launch, recorded on the launch's own stream
     std::mutex prof_mutex;
     std::vector<hipEvent_t> prof_events;
+    std::vector<uint8_t> prof_kind;  // per pair: 0 tile kernel, 1 batch (wave) kernel, 2 piece kernel
     int prof_used = 0;
     int prof_stride = 1, prof_seen = 0;
-    bool prof_on = false;
+    std::atomic<bool> prof_on{false};
 };
+
+// Frees what a stream's entry holds.  The device is current and nothing that uses
+// the blocks is still running.
+void free_stream_scratch(StreamScratch& ss) {
+    (void)hipFree(ss.compute_ws.exchange(nullptr));
+    (void)hipFree(ss.batch);  // from hipMallocAsync: hipFree takes such blocks too
+    ss.batch = nullptr;
+    ss.batch_bytes = 0;
+    if (ss.h_desc) (void)hipHostFree(ss.h_desc);
+    ss.h_desc = ss.d_desc = nullptr;
+    for (hipEvent_t& e : ss.desc_read)
+        if (e) (void)hipEventDestroy(e), e = nullptr;
+    for (hipEvent_t& e : ss.half_read)
+        if (e) (void)hipEventDestroy(e), e = nullptr;
+}
 
 void destroy_ctx(DeviceCtx* c) {  // the device is current
     if (!c) return;
@@ -242,15 +280,8 @@ void destroy_ctx(DeviceCtx* c) {  // the device is current
     if (c->h_bounce) (void)hipHostFree(c->h_bounce);
     for (hipEvent_t e : c->bounce_read)
         if (e) (void)hipEventDestroy(e);
-    for (auto& kv : c->per_stream) {
-        (void)hipFree(kv.second.compute_ws);
-        (void)hipFree(kv.second.batch);
-        if (kv.second.h_desc) (void)hipHostFree(kv.second.h_desc);
-        for (hipEvent_t e : kv.second.desc_read)
-            if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : kv.second.half_read)
-            if (e) (void)hipEventDestroy(e);
-    }
+    for (auto& kv : c->per_stream) free_stream_scratch(*kv.second);
+    c->per_stream.clear();
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
@@ -263,7 +294,11 @@ void destroy_ctx(DeviceCtx* c) {  // the device is current
 }
 
 std::mutex g_ctx_mutex;
-std::vector<DeviceCtx*> g_ctx;  // indexed by device
+std::vector<DeviceCtx*> g_ctx;  // indexed by device; under g_ctx_mutex
+// The same pointers where every call finds its context without a lock (a context
+// lives from the device's first use to sift_shutdown).
+constexpr int kMaxDevices = 64;
+std::atomic<DeviceCtx*> g_ctx_fast[kMaxDevices];
 
 void build_tables(DeviceTables* t) {
     const uint32_t y = gf2_xpow(x2n(), 8ull * kTileBytes);
@@ -339,6 +374,12 @@ int init_ctx(DeviceCtx* c, int device) {  // the device is current
 }
 
 int get_ctx(int device, DeviceCtx** out) {
+    if (device >= 0 && device < kMaxDevices) {
+        if (DeviceCtx* c = g_ctx_fast[device].load(std::memory_order_acquire)) {
+            *out = c;
+            return SIFT_OK;
+        }
+    }
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -370,6 +411,7 @@ int get_ctx(int device, DeviceCtx** out) {
         return rc;
     }
     g_ctx[device] = c;
+    if (device < kMaxDevices) g_ctx_fast[device].store(c, std::memory_order_release);
     *out = c;
     return SIFT_OK;
 }
@@ -387,27 +429,46 @@ const uint32_t* xinv8() {
 
 // Matrices of z^(2^s), z = x^(8 * tpg * kTileBytes), for the group-weighting
 // step.  They depend on (tpg, groups) only, so calls of one size class reuse
-// them; a small per-device cache saves the ~10 GF(2) multiplies.
-void combine_mats(DeviceCtx* c, int64_t tpg, int groups, CombineMats* out) {
-    std::lock_guard<std::mutex> lock(c->mats_mutex);
-    for (auto& e : c->mats_cache)
-        if (e.tpg == tpg && e.groups == groups) {
-            *out = e.m;
-            return;
-        }
+// them; a small cache per calling thread (no lock on the call path) saves the
+// ~10 GF(2) multiplies.
+const CombineMats& combine_mats(int64_t tpg, int groups) {
+    struct Entry {
+        int64_t tpg = -1;
+        int groups = -1;
+        CombineMats m;
+    };
+    thread_local std::array<Entry, 8> cache;
+    thread_local unsigned next = 0;
+    for (auto& e : cache)
+        if (e.tpg == tpg && e.groups == groups) return e.m;
+    Entry& slot = cache[next++ % cache.size()];
+    slot.tpg = tpg;
+    slot.groups = groups;
     uint32_t z = gf2_xpow(x2n(), 8ull * (uint64_t)tpg * kTileBytes);
     for (int s = 0; s < kTreeLevels; ++s) {
         uint32_t r = z;
         for (int k = 0; k < 32; ++k) {
-            out->z[s][k] = r;
+            slot.m.z[s][k] = r;
             r = gf2_mulx(r);
         }
         if ((1 << (s + 1)) < groups) z = gf2_mulmod(z, z);
     }
-    auto& slot = c->mats_cache[c->mats_next++ % c->mats_cache.size()];
-    slot.tpg = tpg;
-    slot.groups = groups;
-    slot.m = *out;
+    return slot.m;
+}
+
+// Measurement: an event pair for the next launch of a kernel of `kind`, if
+// sift_profile_begin asked for one (the stride counts tile-kernel launches only).
+void prof_take(DeviceCtx* c, int kind, hipEvent_t* ev0, hipEvent_t* ev1) {
+    *ev0 = *ev1 = nullptr;
+    if (!c->prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(c->prof_mutex);
+    if (!c->prof_on) return;
+    if (kind == 0 && (c->prof_seen++ % c->prof_stride) != 0) return;
+    if ((size_t)(2 * c->prof_used + 1) >= c->prof_events.size()) return;
+    *ev0 = c->prof_events[2 * c->prof_used];
+    *ev1 = c->prof_events[2 * c->prof_used + 1];
+    c->prof_kind[c->prof_used] = (uint8_t)kind;
+    ++c->prof_used;
 }
 
 // Geometry + launch of one compute(state, buf) over device memory.
@@ -479,24 +540,12 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     t.fuse_final = groups == 1 ? 1u : 0u;
     t.single_launch = (groups > 1 && g_single_launch) ? 1u : 0u;
 
-    CombineMats m;
-    if (groups > 1) {
-        combine_mats(c, tpg, (int)groups, &m);
-    } else {
-        std::memset(&m, 0, sizeof(m));
-    }
+    static const CombineMats no_mats = {};
+    const CombineMats& m = groups > 1 ? combine_mats(tpg, (int)groups) : no_mats;
 
     // measurement: bracket this launch's tile kernel with an event pair
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(c->prof_mutex);
-        if (c->prof_on && (c->prof_seen++ % c->prof_stride) == 0 &&
-            (size_t)(2 * c->prof_used + 1) < c->prof_events.size()) {
-            ev0 = c->prof_events[2 * c->prof_used];
-            ev1 = c->prof_events[2 * c->prof_used + 1];
-            ++c->prof_used;
-        }
-    }
+    prof_take(c, 0, &ev0, &ev1);
     // Measurement (sift_profile_begin/_end): the event pair rides on the tile kernel's own
     // dispatch (hipExtLaunchKernelGGL: its start and end timestamps) -- what rocprofv3
     // reports for the launch -- instead of two marker packets around it, which put 2-3 us
@@ -517,10 +566,44 @@ int launch_compute(DeviceCtx* c, uint32_t state, const uint32_t* d_state_in, con
     return SIFT_OK;
 }
 
-std::atomic<unsigned> g_thread_ids{0};
-volatile uint32_t* result_slot(DeviceCtx* c) {
-    static thread_local const unsigned my_id = g_thread_ids.fetch_add(1);
-    return c->h_results + (size_t)(my_id % kResultSlots) * 16;
+// Pinned result slots of the synchronous entry points: a thread leases one on its
+// first synchronous call and gives it back when it exits, so no two threads ever
+// poll one word.  More than kResultSlots threads alive inside the library at once
+// get an error, not an alias.
+struct SlotPool {
+    std::mutex m;
+    std::vector<int> free_slots;
+    SlotPool() {
+        for (int i = (int)kResultSlots - 1; i >= 0; --i) free_slots.push_back(i);
+    }
+};
+SlotPool& slot_pool() {
+    static SlotPool* pool = new SlotPool;  // leaked on purpose: threads may exit after static destruction
+    return *pool;
+}
+struct SlotLease {
+    int idx = -1;
+    ~SlotLease() {
+        if (idx < 0) return;
+        SlotPool& p = slot_pool();
+        std::lock_guard<std::mutex> lock(p.m);
+        p.free_slots.push_back(idx);
+    }
+};
+int result_slot(DeviceCtx* c, volatile uint32_t** out) {
+    thread_local SlotLease lease;
+    if (lease.idx < 0) {
+        SlotPool& p = slot_pool();
+        std::lock_guard<std::mutex> lock(p.m);
+        if (p.free_slots.empty()) {
+            g_last_error = "more than 1024 threads are using the synchronous entry points at once";
+            return SIFT_ERR_TOO_MANY_THREADS;
+        }
+        lease.idx = p.free_slots.back();
+        p.free_slots.pop_back();
+    }
+    *out = c->h_results + (size_t)lease.idx * 16;
+    return SIFT_OK;
 }
 
 // A tag no other call in flight carries (never 0).
@@ -578,12 +661,35 @@ bool capturing(hipStream_t stream) {
     return st != hipStreamCaptureStatusNone;
 }
 
-// The small scratch block of `stream` (created zeroed on the stream's first
-// call).  c->scratch_mutex is held.
-int stream_block_locked(DeviceCtx* c, hipStream_t stream, uint8_t** blk) {
-    StreamScratch& ss = c->per_stream[stream];
-    if (!ss.compute_ws) {
-        uint32_t* p = nullptr;
+// The scratch entry of `stream` on this device (created empty on first use).  The
+// calling thread remembers the last entry it looked up, so a loop of calls on one
+// stream takes no lock here.
+StreamScratch* stream_scratch(DeviceCtx* c, hipStream_t stream) {
+    struct Last {
+        DeviceCtx* c = nullptr;
+        StreamKey key;
+        uint64_t epoch = 0;
+        StreamScratch* ss = nullptr;
+    };
+    thread_local Last last;
+    const StreamKey key = key_of(stream);
+    const uint64_t epoch = g_scratch_epoch.load(std::memory_order_acquire);
+    if (last.ss && last.c == c && last.key == key && last.epoch == epoch) return last.ss;
+    std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    std::unique_ptr<StreamScratch>& slot = c->per_stream[key];
+    if (!slot) slot.reset(new StreamScratch);
+    last.c = c;
+    last.key = key;
+    last.epoch = g_scratch_epoch.load(std::memory_order_acquire);
+    last.ss = slot.get();
+    return last.ss;
+}
+
+// The small scratch block of a stream (created zeroed on the stream's first call).
+// ss->m is held.
+int stream_block_held(StreamScratch* ss, hipStream_t stream, uint8_t** blk) {
+    uint32_t* p = ss->compute_ws.load(std::memory_order_relaxed);
+    if (!p) {
         SIFT_HIP(hipMalloc(&p, kStreamBlockBytes));
         // On the stream itself: its first kernel is ordered behind the clearing.  (A
         // plain hipMemset runs on the null stream and may still be running when it
@@ -594,10 +700,18 @@ int stream_block_locked(DeviceCtx* c, hipStream_t stream, uint8_t** blk) {
             (void)hipFree(p);
             return fail_hip(e, "hipMemsetAsync(workspace)");
         }
-        ss.compute_ws = p;
+        ss->compute_ws.store(p, std::memory_order_release);
     }
-    *blk = reinterpret_cast<uint8_t*>(ss.compute_ws);
+    *blk = reinterpret_cast<uint8_t*>(p);
     return SIFT_OK;
+}
+int stream_block(StreamScratch* ss, hipStream_t stream, uint8_t** blk) {
+    if (uint32_t* p = ss->compute_ws.load(std::memory_order_acquire)) {
+        *blk = reinterpret_cast<uint8_t*>(p);
+        return SIFT_OK;
+    }
+    std::lock_guard<std::mutex> lock(ss->m);
+    return stream_block_held(ss, stream, blk);
 }
 
 // The compute workspace of `stream`.
@@ -607,11 +721,20 @@ int stream_workspace(DeviceCtx* c, hipStream_t stream, uint32_t** ws) {
                        "sift_crc32_compute_device_static (the library's per-stream scratch cannot go into a graph)";
         return SIFT_ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> lock(c->scratch_mutex);
     uint8_t* blk = nullptr;
-    const int rc = stream_block_locked(c, stream, &blk);
+    const int rc = stream_block(stream_scratch(c, stream), stream, &blk);
     if (rc != SIFT_OK) return rc;
     *ws = reinterpret_cast<uint32_t*>(blk);
+    return SIFT_OK;
+}
+
+// A caller's workspace: the exchange words are 8-byte atomics on 128-byte lines of
+// their own, laid out from the start of the buffer.
+int check_workspace(const void* workspace) {
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) {
+        g_last_error = "workspace must be 256-byte aligned (as hipMalloc returns it)";
+        return SIFT_ERR_INVALID_ARG;
+    }
     return SIFT_OK;
 }
 
@@ -654,6 +777,7 @@ const char* sift_strerror(int status) {
         case SIFT_ERR_NO_DEVICE: return "no usable HIP device";
         case SIFT_ERR_HIP: return "HIP runtime error";
         case SIFT_ERR_INVALID_ARG: return "invalid argument";
+        case SIFT_ERR_TOO_MANY_THREADS: return "too many threads hold a result slot";
         default: return "unknown status";
     }
 }
@@ -667,6 +791,8 @@ int sift_init(int device) {
 
 void sift_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (auto& slot : g_ctx_fast) slot.store(nullptr, std::memory_order_release);
+    g_scratch_epoch.fetch_add(1, std::memory_order_acq_rel);
     for (DeviceCtx* c : g_ctx) {
         if (!c) continue;
         DeviceGuard guard(c->device);
@@ -685,14 +811,48 @@ int sift_reset_workspace(int device) {
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    SIFT_HIP(hipDeviceSynchronize());
+    // No new stream entry and no launch sequence on an existing one while the
+    // blocks are cleared: the map's lock, then every entry's.
     std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    std::vector<std::unique_lock<std::mutex>> held;
+    for (auto& kv : c->per_stream) held.emplace_back(kv.second->m);
+    SIFT_HIP(hipDeviceSynchronize());
     for (auto& kv : c->per_stream) {
-        if (kv.second.compute_ws) SIFT_HIP(hipMemset(kv.second.compute_ws, 0, kStreamBlockBytes));
-        if (kv.second.batch) SIFT_HIP(hipMemset(kv.second.batch, 0, kCutHeadBytes));
+        StreamScratch& ss = *kv.second;
+        if (uint32_t* ws = ss.compute_ws.load()) SIFT_HIP(hipMemset(ws, 0, kStreamBlockBytes));
+        if (ss.batch) SIFT_HIP(hipMemset(ss.batch, 0, kCutHeadBytes));
     }
     SIFT_HIP(hipMemset(c->static_scratch, 0, kStaticScratchWords * sizeof(uint32_t)));
     SIFT_HIP(hipDeviceSynchronize());  // the clearing may outlive hipMemset's return
+    return SIFT_OK;
+}
+
+int sift_release_stream(int device, void* stream) {
+    DeviceCtx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc != SIFT_OK) return rc;
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        g_last_error = "hipSetDevice failed";
+        return SIFT_ERR_HIP;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::unique_ptr<StreamScratch> ss;
+    {
+        std::lock_guard<std::mutex> lock(c->scratch_mutex);
+        auto it = c->per_stream.find(key_of(st));
+        if (it == c->per_stream.end()) return SIFT_OK;  // nothing kept for this stream
+        ss = std::move(it->second);
+        c->per_stream.erase(it);
+        g_scratch_epoch.fetch_add(1, std::memory_order_acq_rel);
+    }
+    // the calls that used the blocks have to be done before the blocks go
+    hipError_t e = hipStreamSynchronize(st);
+    {
+        std::lock_guard<std::mutex> lock(ss->m);
+        free_stream_scratch(*ss);
+    }
+    if (e != hipSuccess) return fail_hip(e, "hipStreamSynchronize(released stream)");
     return SIFT_OK;
 }
 
@@ -708,6 +868,7 @@ int sift_profile_begin(int device, int max_launches, int stride) {
         SIFT_HIP(hipEventCreate(&e));
         c->prof_events.push_back(e);
     }
+    c->prof_kind.assign((size_t)max_launches, 0);
     c->prof_used = 0;
     c->prof_seen = 0;
     c->prof_stride = stride > 0 ? stride : 1;
@@ -721,22 +882,37 @@ int sift_profile_end(int device, double* tile_kernel_ms, int* launches) {
 
 int sift_profile_end_samples(int device, double* tile_kernel_ms, int* launches, float* samples_ms,
                              int max_samples) {
+    double ms[3] = {0, 0, 0};
+    int n[3] = {0, 0, 0};
+    const int rc = sift_profile_end_kernels(device, ms, n, samples_ms, max_samples);
+    if (tile_kernel_ms) *tile_kernel_ms = ms[0];
+    if (launches) *launches = n[0];
+    return rc;
+}
+
+int sift_profile_end_kernels(int device, double kernel_ms[3], int launches[3], float* tile_samples_ms,
+                             int max_samples) {
     DeviceCtx* c = nullptr;
     int rc = get_ctx(device, &c);
     if (rc != SIFT_OK) return rc;
     DeviceGuard guard(device);
     std::lock_guard<std::mutex> lock(c->prof_mutex);
     c->prof_on = false;
-    double total = 0.0;
+    double total[3] = {0, 0, 0};
+    int count[3] = {0, 0, 0};
     for (int i = 0; i < c->prof_used; ++i) {
         SIFT_HIP(hipEventSynchronize(c->prof_events[2 * i + 1]));
         float ms = 0.f;
         SIFT_HIP(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
-        total += ms;
-        if (samples_ms && i < max_samples) samples_ms[i] = ms;
+        const int kind = c->prof_kind[i] < 3 ? c->prof_kind[i] : 0;
+        if (kind == 0 && tile_samples_ms && count[0] < max_samples) tile_samples_ms[count[0]] = ms;
+        total[kind] += ms;
+        ++count[kind];
     }
-    if (tile_kernel_ms) *tile_kernel_ms = total;
-    if (launches) *launches = c->prof_used;
+    for (int k = 0; k < 3; ++k) {
+        if (kernel_ms) kernel_ms[k] = total[k];
+        if (launches) launches[k] = count[k];
+    }
     c->prof_used = 0;
     return SIFT_OK;
 }
@@ -786,6 +962,7 @@ int sift_crc32_compute_device(int device, uint32_t state, const uint32_t* d_stat
         return SIFT_ERR_HIP;
     }
     uint32_t* ws = static_cast<uint32_t*>(workspace);
+    if (ws && (rc = check_workspace(ws)) != SIFT_OK) return rc;
     if (!ws && (rc = stream_workspace(c, static_cast<hipStream_t>(stream), &ws)) != SIFT_OK) return rc;
     return launch_compute(c, state, d_state_in, d_buf, len, 0u, d_out, ws,
                           static_cast<hipStream_t>(stream));
@@ -797,10 +974,7 @@ int sift_crc32_compute_device_static(int device, uint32_t state, const uint32_t*
     // Allocates nothing: the context (tables, this device's scratch address) must
     // exist already, so sift_init(device) has to come first.
     DeviceCtx* c = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_ctx_mutex);
-        if (device >= 0 && device < (int)g_ctx.size()) c = g_ctx[device];
-    }
+    if (device >= 0 && device < kMaxDevices) c = g_ctx_fast[device].load(std::memory_order_acquire);
     if (!c || !c->static_scratch) {
         g_last_error = "sift_crc32_compute_device_static: call sift_init(device) first "
                        "(this entry point allocates nothing, so it cannot set the device up)";
@@ -845,7 +1019,8 @@ int sift_crc32_compute_device_sync(int device, uint32_t state, const void* d_buf
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint32_t* ws = nullptr;
     if ((rc = stream_workspace(c, s, &ws)) != SIFT_OK) return rc;
-    volatile uint32_t* res = result_slot(c);
+    volatile uint32_t* res = nullptr;
+    if ((rc = result_slot(c, &res)) != SIFT_OK) return rc;
     const uint32_t tag = next_tag();
     rc = launch_compute(c, state, nullptr, d_buf, len, 0u, const_cast<uint32_t*>(res), ws, s, tag);
     if (rc != SIFT_OK) return rc;
@@ -873,7 +1048,8 @@ int sift_crc32_compute_host(int device, uint32_t state, const void* buf, uint64_
     const uint8_t* src = static_cast<const uint8_t*>(buf);
     uint32_t* ws = nullptr;
     if ((rc = stream_workspace(c, c->work_stream, &ws)) != SIFT_OK) return rc;
-    volatile uint32_t* res = result_slot(c);
+    volatile uint32_t* res = nullptr;
+    if ((rc = result_slot(c, &res)) != SIFT_OK) return rc;
     const uint32_t tag = next_tag();  // carried by the call's last launch
 
     // Pinned (hipHostMalloc / hipHostRegister) input is device-addressable: the
@@ -1056,9 +1232,8 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         g_last_error = "hipSetDevice failed";
         return SIFT_ERR_HIP;
     }
-    // Descriptors: device arrays and pinned host arrays (device-addressable) are
-    // used in place; pageable host arrays are copied, straight from the caller's
-    // memory, into a stream-ordered allocation.
+    // Descriptors: device arrays are used in place; host arrays are copied or read in
+    // place as described where the copy is made, below.
     const void *dv_off = nullptr, *dv_len = nullptr;
     const Where w_off = where_is(offsets, &dv_off), w_len = where_is(lens, &dv_len);
     if ((w_off == Where::Device) != (w_len == Where::Device)) {
@@ -1114,32 +1289,40 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         g_last_error = "the batch entry points cannot be captured into a graph (their scratch belongs to the stream)";
         return SIFT_ERR_INVALID_ARG;
     }
-    // One batch call at a time issues its launch sequence per device: the scratch
-    // block of a stream is shared by that stream's calls in stream order.
-    std::lock_guard<std::mutex> lock(c->scratch_mutex);
+    // One batch call at a time issues its launch sequence on a stream's scratch
+    // (shared by that stream's calls in stream order); calls on other streams of
+    // the device are not held up.
+    StreamScratch& ss = *stream_scratch(c, st);
+    std::lock_guard<std::mutex> lock(ss.m);
     // Few items (and not the document mode, whose second chunk needs the wave
     // kernel): no filing pass, the piece kernel plans for itself.
     const bool plan = cut && n <= kPlanMax && verify != 2 && g_batch_plan.load() != 0;
     if (plan) {
         uint8_t* blk = nullptr;
-        rc = stream_block_locked(c, st, &blk);
+        rc = stream_block_held(&ss, st, &blk);
         if (rc != SIFT_OK) return rc;
         b.cut.recs = reinterpret_cast<CutRecord*>(blk + kPlanRecsOffset);
         b.cut.wave_max = wave_max;
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     } else if (cut) {
-        StreamScratch& ss = c->per_stream[st];
         const size_t need = kCutHeadBytes + sizeof(CutRecord) * cap_recs + 4 * cap_pieces;
         if (ss.batch_bytes < need) {
-            // grow-only; the old block is freed in stream order, behind the calls that used it
+            // grow-only; the new block is published before the old one is freed (in
+            // stream order, behind the calls that used it), so a failure in between
+            // leaves nothing dangling
             const size_t want = std::max<size_t>(need + need / 2, 512u << 10);
             uint8_t* fresh = nullptr;
             SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&fresh), want, st));
             launch_clear(reinterpret_cast<uint32_t*>(fresh), 64, st);  // the three counters
-            SIFT_HIP(hipGetLastError());
-            if (ss.batch) SIFT_HIP(hipFreeAsync(ss.batch, st));
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                (void)hipFreeAsync(fresh, st);
+                return fail_hip(e, "launch_clear(batch scratch)");
+            }
+            uint8_t* old = ss.batch;
             ss.batch = fresh;
             ss.batch_bytes = want;
+            if (old) SIFT_HIP(hipFreeAsync(old, st));
         }
         uint8_t* blk = ss.batch;
         b.cut.counts = reinterpret_cast<uint32_t*>(blk);
@@ -1162,13 +1345,48 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         }
         for (uint32_t i = 2 * n; i < 2 * kPlanMax; ++i) inl.v[i] = 0;
     }
-    const size_t copy_bytes =
-        use_inline ? 0 : (w_off == Where::Host ? 8ull * n : 0) + (w_len == Where::Host ? 8ull * n : 0);
+    // Host descriptor arrays of up to kDescStageBytes (64 K items when both are host
+    // arrays) are COPIED before the call returns, pageable and pinned alike, so the
+    // caller may refill or free them at once; larger pinned arrays are read in place
+    // by the GPU (they must stay unchanged until `stream` has passed the call),
+    // larger pageable ones go through a stream-ordered allocation.
+    const size_t host_bytes = (w_off != Where::Device ? 8ull * n : 0) + (w_len != Where::Device ? 8ull * n : 0);
+    const bool stage_small = !use_inline && host_bytes && host_bytes <= kDescStageBytes;
+    const bool copy_off = !use_inline && (stage_small ? w_off != Where::Device : w_off == Where::Host);
+    const bool copy_len = !use_inline && (stage_small ? w_len != Where::Device : w_len == Where::Host);
+    const size_t copy_bytes = (copy_off ? 8ull * n : 0) + (copy_len ? 8ull * n : 0);
+    // Whatever happens after this point, the bookkeeping of the descriptor buffers
+    // must follow what was actually queued: `finish` runs on every exit.
     uint8_t* d_desc = nullptr;   // stream-ordered allocation (large descriptor arrays)
     int stage_buf = -1;          // or one of the stream's two pinned buffers (up to 1 MiB)
     int small_slot = -1;         // or one of its ring of small ones
+    bool launched = false;       // a kernel that reads the descriptors may be queued
+    struct Finish {
+        StreamScratch& ss;
+        hipStream_t st;
+        uint8_t*& d_desc;
+        int& stage_buf;
+        int& small_slot;
+        bool& launched;
+        ~Finish() {
+            if (d_desc) (void)hipFreeAsync(d_desc, st);  // stream order: behind the kernels that read it
+            if (stage_buf >= 0 && launched) {
+                if (hipEventRecord(ss.desc_read[stage_buf], st) == hipSuccess) {
+                    ss.desc_used[stage_buf] = true;
+                } else {
+                    (void)hipStreamSynchronize(st);  // no event to wait for later: wait now
+                    ss.desc_used[stage_buf] = false;
+                }
+            }
+            if (small_slot >= 0 && small_slot % (int)(kDescSmallSlots / 2) == (int)(kDescSmallSlots / 2) - 1) {
+                const int half = small_slot / (int)(kDescSmallSlots / 2);
+                // not recorded (error, or nothing launched): half_closed stays false and the
+                // next round of this half waits for the stream instead
+                if (launched && hipEventRecord(ss.half_read[half], st) == hipSuccess) ss.half_closed[half] = true;
+            }
+        }
+    } finish{ss, st, d_desc, stage_buf, small_slot, launched};
     if (copy_bytes && copy_bytes <= kDescStageBytes) {
-        StreamScratch& ss = c->per_stream[st];
         if (!ss.h_desc) {
             uint8_t* h = nullptr;
             SIFT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h),
@@ -1182,9 +1400,9 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         }
         size_t at;  // where the buffer starts in h_desc / d_desc
         if (copy_bytes <= kDescSmallBytes) {
-            small_slot = (int)(ss.small_next++ % kDescSmallSlots);
-            const int half = small_slot / (int)(kDescSmallSlots / 2);
-            if (small_slot % (int)(kDescSmallSlots / 2) == 0) {  // entering a half: its last round must have been read
+            const int slot = (int)(ss.small_next % kDescSmallSlots);
+            const int half = slot / (int)(kDescSmallSlots / 2);
+            if (slot % (int)(kDescSmallSlots / 2) == 0) {  // entering a half: its last round must have been read
                 if (ss.half_begun[half]) {
                     if (ss.half_closed[half]) SIFT_HIP(hipEventSynchronize(ss.half_read[half]));
                     else SIFT_HIP(hipStreamSynchronize(st));  // a call of that round failed before its record
@@ -1192,34 +1410,39 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
                 ss.half_begun[half] = true;
                 ss.half_closed[half] = false;
             }
+            ++ss.small_next;
+            small_slot = slot;
             at = 2 * kDescStageBytes + (size_t)small_slot * kDescSmallBytes;
         } else {
-            stage_buf = (int)(ss.desc_next++ & 1u);
-            if (ss.desc_used[stage_buf]) SIFT_HIP(hipEventSynchronize(ss.desc_read[stage_buf]));
+            const int buf = (int)(ss.desc_next & 1u);
+            if (ss.desc_used[buf]) SIFT_HIP(hipEventSynchronize(ss.desc_read[buf]));
+            ss.desc_used[buf] = false;
+            ++ss.desc_next;
+            stage_buf = buf;
             at = (size_t)stage_buf * kDescStageBytes;
         }
         uint8_t* hp = ss.h_desc + at;
         const uint8_t* dp = ss.d_desc + at;
-        if (w_off == Where::Host) {
+        if (copy_off) {
             std::memcpy(hp, offsets, 8ull * n);
             dv_off = dp;
             hp += 8ull * n;
             dp += 8ull * n;
         }
-        if (w_len == Where::Host) {
+        if (copy_len) {
             std::memcpy(hp, lens, 8ull * n);
             dv_len = dp;
         }
     } else if (copy_bytes) {
         SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_desc), copy_bytes, st));
         uint8_t* d_next = d_desc;
-        if (w_off == Where::Host) {
+        if (copy_off) {
             // pageable source: the runtime has consumed it when the call returns
             SIFT_HIP(hipMemcpyAsync(d_next, offsets, 8ull * n, hipMemcpyHostToDevice, st));
             dv_off = d_next;
             d_next += 8ull * n;
         }
-        if (w_len == Where::Host) {
+        if (copy_len) {
             SIFT_HIP(hipMemcpyAsync(d_next, lens, 8ull * n, hipMemcpyHostToDevice, st));
             dv_len = d_next;
         }
@@ -1238,28 +1461,21 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     const uint64_t wave_chunks = ((uint64_t)n + per_wave - 1) / per_wave;
     const int groups = (int)std::min<uint64_t>((wave_chunks + waves_per_group - 1) / waves_per_group,
                                                (uint64_t)c->groups_max);
+    launched = true;  // from here on a kernel may be queued even if a later step fails
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // measurement: pairs that ride on the dispatches
     if (plan) {
-        launch_pieces(b, c->groups_max, true, use_inline ? &inl : nullptr, st);
+        prof_take(c, 2, &e0, &e1);
+        launch_pieces(b, c->groups_max, true, use_inline ? &inl : nullptr, st, e0, e1);
         SIFT_HIP(hipGetLastError());
     } else {
-        launch_batch(b, groups, st);
+        prof_take(c, 1, &e0, &e1);
+        launch_batch(b, groups, st, e0, e1);
         SIFT_HIP(hipGetLastError());
         if (cut) {
-            launch_pieces(b, c->groups_max, false, nullptr, st);
+            prof_take(c, 2, &e0, &e1);
+            launch_pieces(b, c->groups_max, false, nullptr, st, e0, e1);
             SIFT_HIP(hipGetLastError());
         }
-    }
-    if (d_desc) SIFT_HIP(hipFreeAsync(d_desc, st));
-    if (stage_buf >= 0) {
-        StreamScratch& ss = c->per_stream[st];
-        SIFT_HIP(hipEventRecord(ss.desc_read[stage_buf], st));
-        ss.desc_used[stage_buf] = true;
-    }
-    if (small_slot >= 0 && small_slot % (int)(kDescSmallSlots / 2) == (int)(kDescSmallSlots / 2) - 1) {
-        StreamScratch& ss = c->per_stream[st];
-        const int half = small_slot / (int)(kDescSmallSlots / 2);
-        SIFT_HIP(hipEventRecord(ss.half_read[half], st));
-        ss.half_closed[half] = true;
     }
     return SIFT_OK;
 }
@@ -1305,6 +1521,7 @@ int sift_chunk_crc_device(int device, const void* d_type_and_data, uint64_t data
         return SIFT_ERR_HIP;
     }
     uint32_t* ws = static_cast<uint32_t*>(workspace);
+    if (ws && (rc = check_workspace(ws)) != SIFT_OK) return rc;
     if (!ws && (rc = stream_workspace(c, static_cast<hipStream_t>(stream), &ws)) != SIFT_OK) return rc;
     // container.rs:80-83: new() -> update(type) -> update(data) -> finalize().
     // Two updates over adjacent bytes equal one update over their concatenation.

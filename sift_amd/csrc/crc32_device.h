@@ -203,8 +203,9 @@ struct InlineDesc {
     uint64_t v[2 * kPlanMax];
 };
 
-void launch_batch(const BatchArgs& b, int groups, void* stream);
-void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream);
+void launch_batch(const BatchArgs& b, int groups, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);
+void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream,
+                   void* ev_start = nullptr, void* ev_stop = nullptr);
 void launch_clear(uint32_t* words, int n, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);

@@ -1849,25 +1849,38 @@ void launch_clear(uint32_t* words, int n, void* stream) {
     hipLaunchKernelGGL(crc32_clear_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), words, n);
 }
 
-void launch_batch(const BatchArgs& b, int groups, void* stream) {
+// With an event pair the launch goes through hipExtLaunchKernelGGL: the events take the
+// dispatch's own start and end timestamps (measurement only, sift_profile_begin).
+#define SIFT_LAUNCH(kernel, grid, s, e0, e1, ...)                                                      \
+    do {                                                                                               \
+        if (e0 && e1)                                                                                  \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, s, static_cast<hipEvent_t>(e0), \
+                                  static_cast<hipEvent_t>(e1), 0, __VA_ARGS__);                        \
+        else                                                                                           \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                 \
+    } while (0)
+
+void launch_batch(const BatchArgs& b, int groups, void* stream, void* ev_start, void* ev_stop) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (b.verify) {
-        case 0: hipLaunchKernelGGL(crc32_batch_kernel<0>, dim3(groups), dim3(kThreads), 0, s, b); break;
-        case 1: hipLaunchKernelGGL(crc32_batch_kernel<1>, dim3(groups), dim3(kThreads), 0, s, b); break;
-        case 2: hipLaunchKernelGGL(crc32_batch_kernel<2>, dim3(groups), dim3(kThreads), 0, s, b); break;
-        default: hipLaunchKernelGGL(crc32_batch_kernel<3>, dim3(groups), dim3(kThreads), 0, s, b); break;
+        case 0: SIFT_LAUNCH(crc32_batch_kernel<0>, groups, s, ev_start, ev_stop, b); break;
+        case 1: SIFT_LAUNCH(crc32_batch_kernel<1>, groups, s, ev_start, ev_stop, b); break;
+        case 2: SIFT_LAUNCH(crc32_batch_kernel<2>, groups, s, ev_start, ev_stop, b); break;
+        default: SIFT_LAUNCH(crc32_batch_kernel<3>, groups, s, ev_start, ev_stop, b); break;
     }
 }
 
-void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream) {
+void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream, void* ev_start,
+                   void* ev_stop) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (plan && inl)
-        hipLaunchKernelGGL((crc32_pieces_kernel<true, true>), dim3(groups), dim3(kThreads), 0, s, b, *inl);
+        SIFT_LAUNCH((crc32_pieces_kernel<true, true>), groups, s, ev_start, ev_stop, b, *inl);
     else if (plan)
-        hipLaunchKernelGGL((crc32_pieces_kernel<true, false>), dim3(groups), dim3(kThreads), 0, s, b, NoInline{0u});
+        SIFT_LAUNCH((crc32_pieces_kernel<true, false>), groups, s, ev_start, ev_stop, b, NoInline{0u});
     else
-        hipLaunchKernelGGL((crc32_pieces_kernel<false, false>), dim3(groups), dim3(kThreads), 0, s, b, NoInline{0u});
+        SIFT_LAUNCH((crc32_pieces_kernel<false, false>), groups, s, ev_start, ev_stop, b, NoInline{0u});
 }
+#undef SIFT_LAUNCH
 
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,
                   bool use_y, void* stream, void* ev_start, void* ev_stop) {

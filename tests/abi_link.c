@@ -8,7 +8,7 @@
 
 int main(void) {
     void *fns[] = {
-        (void *)sift_strerror, (void *)sift_last_error, (void *)sift_init, (void *)sift_shutdown, (void *)sift_reset_workspace, (void *)sift_profile_end_samples,
+        (void *)sift_strerror, (void *)sift_last_error, (void *)sift_init, (void *)sift_shutdown, (void *)sift_reset_workspace, (void *)sift_release_stream, (void *)sift_profile_end_samples, (void *)sift_profile_end_kernels,
         (void *)sift_crc32_workspace_bytes, (void *)sift_profile_begin, (void *)sift_profile_end,
         (void *)sift_tune, (void *)sift_crc32_compute_device, (void *)sift_crc32_compute_device_sync,
         (void *)sift_crc32_compute_device_static,

@@ -3,6 +3,7 @@
 //   batch_bench                 runs the whole table
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,47 @@ int main(int argc, char** argv) {
         }
     };
     preheat(80);
+
+    // batch_bench compute [<bytes>]: sift_crc32_compute_device back to back over rotating slices of the
+    // blob (caller's workspace), host issue time and wall time per call; under rocprofv3 --kernel-trace
+    // the same run gives the kernel's duration and its start-to-start interval (tools/start_to_start.py)
+    if (argc >= 2 && !strcmp(argv[1], "compute")) {
+        const size_t only = argc >= 3 ? strtoull(argv[2], nullptr, 0) : 0;
+        void* ws = nullptr;
+        CK(hipMalloc(&ws, sift_crc32_workspace_bytes()));
+        CK(hipMemset(ws, 0, sift_crc32_workspace_bytes()));
+        CK(hipDeviceSynchronize());
+        printf("{\"rows\": [\n");
+        bool first_row = true;
+        for (size_t size : {(size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)256 << 20}) {
+            if (only && size != only) continue;
+            const size_t nsl = std::max<size_t>(2, std::min<size_t>(total / size, std::max<size_t>(8, (512u << 20) / size)));
+            const size_t pitch = (total / nsl) / 4096 * 4096;
+            const int calls = size <= (16u << 20) ? 2000 : 400;
+            preheat(40);
+            double best_issue = 1e9, best_wall = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                for (int i = 0; i < 20; ++i)
+                    SK(sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, blob + (i % nsl) * pitch, size, d_out, ws, s));
+                CK(hipStreamSynchronize(s));
+                const double t0 = now();
+                for (int i = 0; i < calls; ++i)
+                    SK(sift_crc32_compute_device(0, 0xFFFFFFFFu, nullptr, blob + (i % nsl) * pitch, size, d_out, ws, s));
+                const double t_issue = now() - t0;
+                CK(hipStreamSynchronize(s));
+                const double t_wall = now() - t0;
+                best_issue = std::min(best_issue, t_issue / calls);
+                best_wall = std::min(best_wall, t_wall / calls);
+            }
+            printf("%s {\"kind\": \"compute_async\", \"bytes\": %zu, \"slices\": %zu, \"calls\": %d, "
+                   "\"issue_us_per_call\": %.2f, \"wall_us_per_call\": %.2f, \"GBps_wall\": %.1f}",
+                   first_row ? "" : ",\n", size, nsl, calls, best_issue * 1e6, best_wall * 1e6, (double)size / best_wall / 1e9);
+            first_row = false;
+            fflush(stdout);
+        }
+        printf("\n]}\n");
+        return 0;
+    }
 
     // batch_bench chunk <bytes>: only Chunk::read on one chunk of that many data bytes (for rocprofv3)
     const bool only_items = argc >= 3 && !strcmp(argv[1], "items");  // batch_bench items <bytes>: one crc_batch size (for rocprofv3 --pmc)
