@@ -48,14 +48,18 @@ def compute(crc: int, buf, device: int | None = None) -> int:
     return out.value
 
 
-def compute_async(crc, buf: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor | None = None) -> None:
+def compute_async(crc, buf: torch.Tensor, out: torch.Tensor, workspace: torch.Tensor | None = None,
+                  stream: int | None = None) -> None:
     """Asynchronous form on the current stream: result lands in out[0] (int32/uint32
-    device tensor).  `crc` is an int or a 1-element device tensor holding the state."""
+    device tensor).  `crc` is an int or a 1-element device tensor holding the state.
+    `stream`: a raw hipStream_t the caller already holds (a loop of calls need not
+    ask torch for the current stream every time)."""
     dev = buf.device.index
     state_imm, state_ptr = (0, crc.data_ptr()) if isinstance(crc, torch.Tensor) else (crc & 0xFFFFFFFF, None)
     ws = workspace.data_ptr() if workspace is not None else None
     check(lib.sift_crc32_compute_device(
-        dev, state_imm, state_ptr, buf.data_ptr(), buf.numel(), out.data_ptr(), ws, _stream_ptr(dev)))
+        dev, state_imm, state_ptr, buf.data_ptr(), buf.numel(), out.data_ptr(), ws,
+        _stream_ptr(dev) if stream is None else stream))
 
 
 def workspace_bytes() -> int:

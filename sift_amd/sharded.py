@@ -30,12 +30,12 @@ def stitch(pairs: Sequence[Sequence[int]]) -> int:
 
 
 def local_state_async(crc: int, local: torch.Tensor, rank: int, pair: torch.Tensor,
-                      workspace: Optional[torch.Tensor] = None) -> None:
+                      workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
     """Launch this rank's reduction on the current stream.  `pair` is a
     2-element int64 device tensor the caller initialised to [0, local.numel()];
     the kernel stores the u32 state into the low half of pair[0] (little
     endian).  Nothing else is launched, so a step is the reduction alone."""
-    _crc.compute_async(crc if rank == 0 else 0, local, pair[0:1].view(torch.int32), workspace)
+    _crc.compute_async(crc if rank == 0 else 0, local, pair[0:1].view(torch.int32), workspace, stream)
 
 
 def sharded_compute(crc: int, local, group=None,

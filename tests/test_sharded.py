@@ -122,4 +122,7 @@ def test_bench_dry_collective_two_ranks():
         capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert lines and json.loads(lines[-1]) == {"dry_collective": "ok", "world": 2, "steps": 3}
+    # "verified": the bench's untimed self-check of the exchange (verify_exchange) passed on
+    # both ranks -- and, inside the dry run, a deliberately wrong rank was caught by it
+    assert lines and json.loads(lines[-1]) == {"dry_collective": "ok", "world": 2, "steps": 3,
+                                               "verified": True, "ranks_seen": 2}

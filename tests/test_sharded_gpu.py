@@ -81,3 +81,6 @@ def test_bench_rehearses_its_collectives_on_one_gpu():
     assert outs[0]["config"]["result"] == outs[1]["config"]["result"]
     assert "rehearsed" in outs[1]["config"]["parallelism"]
     assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
+    # the untimed self-check of the exchange ran over RCCL (one rank) and passed
+    assert outs[1]["config"]["verified"] is True and outs[1]["config"]["ranks_seen"] == 1
+    assert "verified" not in outs[0]["config"]
