@@ -333,6 +333,18 @@ void build_tables(DeviceTables* t) {
         }
     }
     for (uint64_t h = 0; h < 16; ++h) t->XinvH[h] = gf2_xpow(x2n(), 0xFFFFFFFFull - 8ull * h);
+    // the batch kernel's LDS image (layout: KiLane in crc32_kernels.hip)
+    for (uint32_t b = 0; b < 256; ++b)
+        for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t c = 0; c < 8; ++c) {
+                t->batch_image[b * 64 + 4 * c + k] = t->Y256[k * 256 + b];             // block 0: G
+                t->batch_image[b * 64 + 32 + 4 * c + k] = t->X[k * 256 + b];           //          X
+                t->batch_image[32768 + b * 32 + 4 * c + k] = t->Y1[k * 256 + b];       // block 2: Y1
+            }
+            for (uint32_t j = 0; j < 4; ++j)
+                for (uint32_t c = 0; c < 4; ++c)
+                    t->batch_image[16384 + b * 64 + 16 * j + 4 * c + k] = t->K[j][k * 256 + b];  // block 1: K0..K3
+        }
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {

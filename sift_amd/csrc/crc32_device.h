@@ -77,6 +77,9 @@ struct DeviceTables {
     uint32_t C1[32];         // C1[i] = x^(128*kThreads) * x^i: from one of a lane's vectors to its next
     uint32_t X2[32][32];     // X2[s][k] = x^(2^s) * x^k: row k of the matrix of x^(2^s) (piece weights)
     uint32_t XinvH[16];      // XinvH[h] = x^(-8h): folds a starting register into a vector with h pad bytes
+    // The batch kernel's LDS, word for word (160 KiB; layout: KiLane in crc32_kernels.hip):
+    // Y256 and X by byte value in rows of 256 B, K[0..3] likewise, Y1 in rows of 128 B.
+    __attribute__((aligned(16))) uint32_t batch_image[40960];
 };
 
 // Arguments of the tile kernel.

@@ -82,6 +82,89 @@ __device__ __forceinline__ uint32_t table_step_byte(uint32_t c, uint32_t byte, P
     return ldsT8[(c ^ byte) & 0xffu] ^ (c >> 8);
 }
 
+// ---------------------------------------------------------------------------
+// Row-interleaved LDS tables of the batch kernel.
+//
+// A multiply-by-constant table T[k][b] (k = byte position 0..3, b = byte value) used to
+// sit in LDS as [k][b][copy]: a lookup was a byte extract, a shift-add and the read, and a
+// lane group's 32 lookups were conflict-free only with 32 copies (128 KiB a table).  Here a
+// table is laid out BY BYTE VALUE: row b holds, for each of C copies, the four entries
+// T[0..3][b] next to each other (word 4c + k), and lane l makes its four lookups of one
+// multiply in the order k_j = ((l & 3) + j) & 3, copy c = (l >> 2) & (C - 1).  For every j
+// the 32 lanes of a ds_read_b32 lane group then read 4 C different banks whatever the data:
+// conflict-free with C = 8 (32 KiB a table instead of 128), two-way with C = 4 (lanes l and
+// l + 16 share).  And with rows of 256 bytes the whole address is ONE v_perm_b32: byte 1 =
+// the operand's byte k_j, byte 0 = the lane's offset in the row, byte 2 = the 64 KiB block:
+//     block 0  [0, 64 K)      rows of 256 B:  G = x^(8*256) C = 8 | X = x^32 C = 8
+//     block 1  [64 K, 128 K)  rows of 256 B:  K0 | K1 | K2 | K3 (x^(128 * 2^j)), C = 4 each
+//     block 2  [128 K, 160 K) rows of 128 B:  Y1 = x^(8*1024) C = 8 (the wave path: its
+//                                             address is the permute shifted right by one)
+// The reference's own CRC_TABLE (crc.rs:2-20) is X's k = 3 slice: (b << 24) * x^32 = b * x^8.
+// The image is built on the host (DeviceTables::batch_image) and copied in 16 bytes a lane.
+// The tables start at LDS address 0 (the kernel's one __shared__ array; checked in its
+// prologue), and a lookup reads the absolute address permute + IMM, so that IMM rides in
+// the ds_read's offset field: with the array's base passed down as a pointer the callee
+// had to add it to every address (one more instruction a lookup).
+typedef __attribute__((address_space(3))) const uint8_t* LdsBytes;
+typedef __attribute__((address_space(3))) const uint32_t* LdsWord;
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_read(uint32_t at) {
+    return *reinterpret_cast<LdsWord>(static_cast<uintptr_t>(at + (uint32_t)IMM));
+}
+struct KiLane {
+    uint32_t sel[4];  // v_perm_b32 selectors, step j: [S1 byte (j & 1), operand byte k_j, S1 byte 2, 0]
+    uint32_t p8, q8;  // C = 8 rows of block 0: row offsets of steps 0, 1 (p8) and 2, 3 (q8), block byte 0
+};
+__device__ __forceinline__ KiLane ki_lane(uint32_t lane) {
+    KiLane L;
+    const uint32_t s = lane & 3u, c8 = (lane >> 2) & 7u;
+    uint32_t o[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t k = (s + j) & 3u;
+        L.sel[j] = 0x0c020000u | ((4u + k) << 8) | (j & 1u);
+        o[j] = 16u * c8 + 4u * k;
+    }
+    L.p8 = o[0] | (o[1] << 8);
+    L.q8 = o[2] | (o[3] << 8);
+    return L;
+}
+enum : int { kTabG = 0, kTabX = 128 };                                   // block 0, C = 8
+enum : int { kTabK0 = 0, kTabK1 = 64, kTabK2 = 128, kTabK3 = 192 };      // block 1, C = 4
+constexpr int kBatchLdsWords = 40960;                                    // 160 KiB: all of the CU's LDS
+// a * (the table's constant): four lookups, one v_perm_b32 each.  p, q: the lane's row
+// offsets (and block) for the table's geometry; IMM: where the table starts in a row.
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul(uint32_t a, const KiLane& L, uint32_t p, uint32_t q) {
+    const uint32_t a0 = __builtin_amdgcn_perm(a, p, L.sel[0]), a1 = __builtin_amdgcn_perm(a, p, L.sel[1]);
+    const uint32_t a2 = __builtin_amdgcn_perm(a, q, L.sel[2]), a3 = __builtin_amdgcn_perm(a, q, L.sel[3]);
+    return ki_read<IMM>(a0) ^ ki_read<IMM>(a1) ^ ki_read<IMM>(a2) ^ ki_read<IMM>(a3);
+}
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul8(uint32_t a, const KiLane& L) {  // G, X
+    return ki_mul<IMM>(a, L, L.p8, L.q8);
+}
+// the C = 4 rows of block 1: the same offsets without the copy's top bit, block byte 1
+__device__ __forceinline__ uint32_t ki_p4(uint32_t p8) { return (p8 & 0x3f3fu) | 0x10000u; }
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul4(uint32_t a, const KiLane& L, uint32_t p4, uint32_t q4) {
+    return ki_mul<IMM>(a, L, p4, q4);
+}
+// block 2 (rows of 128 bytes): the permute of doubled offsets with block byte 4, halved
+__device__ __forceinline__ uint32_t ki_py(uint32_t p8) { return (p8 << 1) | 0x40000u; }
+__device__ __forceinline__ uint32_t ki_muly(uint32_t a, const KiLane& L, uint32_t py, uint32_t qy) {
+    const uint32_t a0 = __builtin_amdgcn_perm(a, py, L.sel[0]) >> 1, a1 = __builtin_amdgcn_perm(a, py, L.sel[1]) >> 1;
+    const uint32_t a2 = __builtin_amdgcn_perm(a, qy, L.sel[2]) >> 1, a3 = __builtin_amdgcn_perm(a, qy, L.sel[3]) >> 1;
+    return ki_read<0>(a0) ^ ki_read<0>(a1) ^ ki_read<0>(a2) ^ ki_read<0>(a3);
+}
+// One byte of the reference's recurrence WITH its table (crc.rs:31), the table being X's
+// k = 3 slice; t8 = the lane's offset of such an entry in a row (ki_t8).
+__device__ __forceinline__ uint32_t ki_t8(uint32_t lane) { return 16u * ((lane >> 2) & 7u) + 12u; }
+__device__ __forceinline__ uint32_t ki_step_byte(uint32_t c, uint32_t byte, uint32_t t8) {
+    const uint32_t at = __builtin_amdgcn_perm(c ^ byte, t8, 0x0c0c0400u);  // [t8, low byte of c ^ byte, 0, 0]
+    return ki_read<kTabX>(at) ^ (c >> 8);
+}
+
 // One Horner step for a lane's four words: acc <- acc * y + w.
 #ifndef SIFT_ABLATE_WORDS
 #define SIFT_ABLATE_WORDS 4  // timing-only builds thin the step to fewer real multiplies
@@ -627,11 +710,13 @@ __device__ __forceinline__ void wave_request(const uint8_t* ptr, uint64_t len, u
 // is a chain of dependent lookups and shuffles with nothing in flight, and the next
 // span's first tile used to be asked for only behind it -- two idle stretches per span.
 __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, uint32_t state,
-                                             const uint32_t* ldsY, const uint32_t* ldsG, const uint32_t* ldsX,
-                                             const uint32_t* ldsK, const uint32_t* ldsT8, uint32_t lane,
-                                             uint32_t lane32, const WaveHead& hd, const uint8_t* np, uint64_t nl,
-                                             WaveHead& nxt) {
-    const uint32_t lw = lane32 & (uint32_t)(kWaveRepl - 1), lx = lane32 & (uint32_t)(kXRepl - 1);  // table copies
+                                             const KiLane& L, uint32_t lane, const WaveHead& hd, const uint8_t* np,
+                                             uint64_t nl, WaveHead& nxt) {
+    const uint32_t py = ki_py(L.p8), qy = ki_py(L.q8);  // the wave table's rows (block 2)
+    auto horner_y = [&](u32x4& a, const u32x4 w) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = ki_muly(a[c], L, py, qy) ^ w[c];
+    };
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
     const int64_t nvec = (int64_t)(v1 - v0);  // >= 1, body >= 17 bytes
@@ -662,7 +747,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     GlobalVec p = vbase + vi;
     if (left > 0) {
         const u32x4 w = fold_state(hd.t1, vi, h, state);
-        horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
+        horner_y(acc, w);
         p += 64;
         --left;
     }
@@ -675,22 +760,22 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
             const u32x4 n0 = __builtin_nontemporal_load(p);
             const u32x4 n1 = __builtin_nontemporal_load(p + 64);
             p += 128;
-            horner_tab<kWaveReplLog2>(acc, c0, ldsY, lw);
-            horner_tab<kWaveReplLog2>(acc, c1, ldsY, lw);
+            horner_y(acc, c0);
+            horner_y(acc, c1);
             c0 = n0;
             c1 = n1;
         }
-        horner_tab<kWaveReplLog2>(acc, c0, ldsY, lw);
-        horner_tab<kWaveReplLog2>(acc, c1, ldsY, lw);
+        horner_y(acc, c0);
+        horner_y(acc, c1);
     }
     if (left > 0) {
         const u32x4 w = __builtin_nontemporal_load(p);
-        horner_tab<kWaveReplLog2>(acc, w, ldsY, lw);
+        horner_y(acc, w);
     }
     wave_request(np, nl, lane, nxt);
     uint32_t r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
+    for (int c = 0; c < 4; ++c) r = ki_mul8<kTabX>(r ^ acc[c], L);
     // the 64 lanes joined pairwise, as the lanes of a group are: at step j the lane whose
     // bit j is clear holds the earlier 2^j vectors, multiplies by x^(128 * 2^j) and takes
     // in its partner's.  Steps 0-3 look up the lane-join tables, step 4 the group path's
@@ -698,14 +783,17 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // place, x^(128 * (63 - lane)), in 32 shift-and-xor steps: some 220 instructions a
     // span against 90 here.  The time per span did not change -- this path waits for
     // memory -- but the kernel needs 9-15 registers fewer and no longer spills.)
-    const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
-    r = mul_tab<kGroupReplLog2>(r, ldsG, l4) ^ __shfl_xor(r, 16, 64);
-    r = mul_tab<kGroupReplLog2>(mul_tab<kGroupReplLog2>(r, ldsG, l4), ldsG, l4) ^ __shfl_xor(r, 32, 64);
+    const uint32_t p4 = ki_p4(L.p8), q4 = ki_p4(L.q8);
+    r = ki_mul4<kTabK0>(r, L, p4, q4) ^ __shfl_xor(r, 1, 64);
+    r = ki_mul4<kTabK1>(r, L, p4, q4) ^ __shfl_xor(r, 2, 64);
+    r = ki_mul4<kTabK2>(r, L, p4, q4) ^ __shfl_xor(r, 4, 64);
+    r = ki_mul4<kTabK3>(r, L, p4, q4) ^ __shfl_xor(r, 8, 64);
+    r = ki_mul8<kTabG>(r, L) ^ __shfl_xor(r, 16, 64);
+    r = ki_mul8<kTabG>(ki_mul8<kTabG>(r, L), L) ^ __shfl_xor(r, 32, 64);
     r = __shfl(r, 0, 64);
     // trailing bytes: every lane walks them alike (no divergence, no broadcast)
-    for (uint32_t i = 0; i < tail_len; ++i) r = table_step_byte(r, __shfl(tb, (int)i, 64), ldsT8);
+    const uint32_t t8 = ki_t8(lane);
+    for (uint32_t i = 0; i < tail_len; ++i) r = ki_step_byte(r, __shfl(tb, (int)i, 64), t8);
     return r;
 }
 
@@ -770,22 +858,19 @@ __device__ __forceinline__ void group_request(const uint8_t* ptr, uint32_t len, 
 
 template <int GW, int NCH, bool ENDF>
 __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
-                                                   const uint32_t* ldsG_, const uint32_t* ldsX_,
-                                                   const uint32_t* ldsK_, const uint32_t* ldsT8_, uint32_t lane,
+                                                   const KiLane& L, uint32_t lane,
                                                    const GroupLoads<NCH>* pre = nullptr) {
     static_assert((GW == 8 && NCH == 2) || (GW == 4 && (NCH == 4 || NCH == 2)) || (GW == 2 && NCH == 2), "group shape");
     constexpr int LG = GW == 8 ? 3 : GW == 4 ? 2 : 1;   // log2(GW): steps of the lane join
     constexpr int LCH = NCH == 4 ? 2 : 1;               // log2(chains per lane)
     constexpr bool ONE_ROUND = GW < 8;                  // the span is at most GW * NCH vectors
-    // A call passes generic pointers; say which memory they point into, or every
+    // A call passes a generic pointer; say which memory it points into, or every
     // table lookup becomes a flat load that waits on both counters.
-    typedef __attribute__((address_space(3))) const uint32_t* LdsPtr;
     typedef u32x4 __attribute__((aligned(1))) u32x4_u;
     typedef __attribute__((address_space(1))) const u32x4_u* GlobalVecU;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
-    const LdsPtr ldsG = (LdsPtr)ldsG_, ldsX = (LdsPtr)ldsX_, ldsK = (LdsPtr)ldsK_, ldsT8 = (LdsPtr)ldsT8_;
     const uint32_t lg = lane & (uint32_t)(GW - 1);
-    const uint32_t l4 = lane & (uint32_t)(kGroupRepl - 1), lx = lane & (uint32_t)(kXRepl - 1);  // table copies
+    const uint32_t p4 = ki_p4(L.p8), q4 = ki_p4(L.q8);  // rows of the lane-join tables (block 1)
     // Two framings.  ENDF: the span is framed from its END: vector v covers the 16 bytes
     // that end 16 * (nvec - 1 - v) bytes before the span's end, whatever their address (the
     // hardware takes 16-byte loads at any byte address; off a 4-byte boundary they stream
@@ -898,10 +983,10 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
                 for (int c = 0; c < NCH; ++c) {
                     if (ha) {  // two words at a time: half the lookups in flight, half the registers
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                        for (int k = 0; k < 2; ++k) ch[c][k] = ki_mul8<kTabG>(ch[c][k], L) ^ w[c][k];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 2; k < 4; ++k) ch[c][k] = mul_tab<kGroupReplLog2>(ch[c][k], ldsG, l4) ^ w[c][k];
+                        for (int k = 2; k < 4; ++k) ch[c][k] = ki_mul8<kTabG>(ch[c][k], L) ^ w[c][k];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -916,7 +1001,7 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
         for (int c = NCH - 2; c >= 0; --c) {
             if (__any(ntile > c + 1)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = mul_x32(acc[k], ldsK + LG * 1024);
+                for (int k = 0; k < 4; ++k) acc[k] = ki_mul4<64 * LG>(acc[k], L, p4, q4);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
@@ -931,16 +1016,18 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
     // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
     uint32_t r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = mul_tab<kXReplLog2>(r ^ acc[c], ldsX, lx);
-#pragma unroll
-    for (int j = 0; j < LG; ++j) r = mul_x32(r, ldsK + j * 1024) ^ __shfl_xor(r, 1 << j, 64);
+    for (int c = 0; c < 4; ++c) r = ki_mul8<kTabX>(r ^ acc[c], L);
+    r = ki_mul4<kTabK0>(r, L, p4, q4) ^ __shfl_xor(r, 1, 64);
+    if constexpr (LG > 1) r = ki_mul4<kTabK1>(r, L, p4, q4) ^ __shfl_xor(r, 2, 64);
+    if constexpr (LG > 2) r = ki_mul4<kTabK2>(r, L, p4, q4) ^ __shfl_xor(r, 4, 64);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
     // meaningful register, the others walk along
     if constexpr (!ENDF) {
+        const uint32_t t8 = ki_t8(lane);
 #pragma unroll
         for (uint32_t i = 0; i < 15u; ++i) {
             if (!__any(i < tail_len)) break;
-            const uint32_t step = table_step_byte(r, (tw[i >> 2] >> (8u * (i & 3u))) & 0xffu, ldsT8);
+            const uint32_t step = ki_step_byte(r, (tw[i >> 2] >> (8u * (i & 3u))) & 0xffu, t8);
             r = i < tail_len ? step : r;
         }
     }
@@ -949,9 +1036,8 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
 
 template <int GW, int NCH, bool ENDF>
 __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
-                                              const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
-                                              const uint32_t* ldsT8, uint32_t lane) {
-    return group_crc_body<GW, NCH, ENDF>(ptr, len, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+                                              KiLane L, uint32_t lane) {
+    return group_crc_body<GW, NCH, ENDF>(ptr, len, state, on, L, lane);
 }
 
 // Two passes in one: both spans' vectors are requested before the first is worked on, so a
@@ -959,31 +1045,29 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
 // the low (a) and high (b) word.
 template <int GW, int NCH, bool ENDF>
 __device__ __forceinline__ uint64_t group_crc_pair_body(const uint8_t* pa, uint32_t la, bool ona, const uint8_t* pb,
-                                                        uint32_t lb, bool onb, uint32_t state, const uint32_t* ldsG,
-                                                        const uint32_t* ldsX, const uint32_t* ldsK,
-                                                        const uint32_t* ldsT8, uint32_t lane) {
+                                                        uint32_t lb, bool onb, uint32_t state, const KiLane& L,
+                                                        uint32_t lane) {
     GroupLoads<NCH> ga, gb;
     group_request<GW, NCH, ENDF>(pa, la, ona, lane, ga);
     group_request<GW, NCH, ENDF>(pb, lb, onb, lane, gb);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t ra = group_crc_body<GW, NCH, ENDF>(pa, la, state, ona, ldsG, ldsX, ldsK, ldsT8, lane, &ga);
+    const uint32_t ra = group_crc_body<GW, NCH, ENDF>(pa, la, state, ona, L, lane, &ga);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t rb = group_crc_body<GW, NCH, ENDF>(pb, lb, state, onb, ldsG, ldsX, ldsK, ldsT8, lane, &gb);
+    const uint32_t rb = group_crc_body<GW, NCH, ENDF>(pb, lb, state, onb, L, lane, &gb);
     return ((uint64_t)rb << 32) | ra;
 }
 template <int GW, int NCH, bool ENDF>
 __device__ __attribute__((noinline)) uint64_t group_crc_pair(const uint8_t* pa, uint32_t la, bool ona,
                                                              const uint8_t* pb, uint32_t lb, bool onb, uint32_t state,
-                                                             const uint32_t* ldsG, const uint32_t* ldsX,
-                                                             const uint32_t* ldsK, const uint32_t* ldsT8,
-                                                             uint32_t lane) {
-    return group_crc_pair_body<GW, NCH, ENDF>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane);
+                                                             KiLane L, uint32_t lane) {
+    return group_crc_pair_body<GW, NCH, ENDF>(pa, la, ona, pb, lb, onb, state, L, lane);
 }
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
 // bytes are fetched first, all at once, then walked with the reference's table step.
 __device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr_, uint32_t len, uint32_t state, bool on,
-                                             const uint32_t* ldsT8) {
+                                             uint32_t lane) {
+    const uint32_t t8 = ki_t8(lane);
     uint32_t r = state;
     on = on && len != 0u;
     typedef __attribute__((address_space(1))) const uint8_t* GlobalByte;  // see wave_crc
@@ -1003,7 +1087,7 @@ __device__ __forceinline__ uint32_t lane_crc(const uint8_t* ptr_, uint32_t len, 
     if (on) {
 #pragma unroll
         for (uint32_t k = 0; k < 31u; ++k)
-            if (k < len) r = table_step_byte(r, (w[k >> 2] >> (8u * (k & 3u))) & 0xffu, ldsT8);
+            if (k < len) r = ki_step_byte(r, (w[k >> 2] >> (8u * (k & 3u))) & 0xffu, t8);
     }
     return r;
 }
@@ -1156,14 +1240,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 template <int MODE>
 __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_t sp, uint64_t sl,
                                           uint32_t item, uint32_t cont, uint32_t dlen, bool may_file,
-                                          uint32_t& res, bool& filed, const uint32_t* ldsY,
-                                          const uint32_t* ldsG, const uint32_t* ldsX, const uint32_t* ldsK,
-                                          const uint32_t* ldsT8, uint32_t lane, uint32_t lane32) {
+                                          uint32_t& res, bool& filed, const KiLane& L,
+                                          uint32_t lane) {
     const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
     // under 32 bytes: a lane each
     const bool tiny = want && sl <= (uint64_t)kTinyMax;
     if (__any(tiny)) {
-        const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, ldsT8);
+        const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, lane);
         if (tiny) res = r;
     }
     // 32 .. 4080 bytes: a group of lanes each -- 2 lanes while no such span of the turn
@@ -1196,13 +1279,11 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             const uint32_t la = __shfl((uint32_t)sl, ma, 64), lb = __shfl((uint32_t)sl, mb, 64);
             // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
             // inlined as well makes the document mode spill)
-            const uint64_t rr = longest <= 64u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG,
-                                                                                  ldsX, ldsK, ldsT8, lane)
-                                : longest <= 128u ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX,
-                                                                               ldsK, ldsT8, lane)
+            const uint64_t rr = longest <= 64u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
+                                : longest <= 128u ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
                                 : longest <= (uint32_t)kGroup4Max
-                                    ? group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane)
-                                    : group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, ldsG, ldsX, ldsK, ldsT8, lane);
+                                    ? group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, L, lane)
+                                    : group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane);
             const uint32_t k = below - first;  // which of the 2 * per_pass spans, for the lanes it concerns
             const int src = (int)((k & (per_pass - 1u)) << lgw);
             const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
@@ -1215,11 +1296,11 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
             const uint32_t l = __shfl((uint32_t)sl, mine, 64);
             uint32_t r;
-            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
-            else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
-            else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
-            else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
-            else r = group_crc<8, 2, false>(p, l, state, on, ldsG, ldsX, ldsK, ldsT8, lane);
+            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, L, lane);
+            else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, L, lane);
+            else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, L, lane);
+            else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, L, lane);
+            else r = group_crc<8, 2, false>(p, l, state, on, L, lane);
             // back to the lanes that hold the spans: rank - first is the group that did it
             const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) << lgw), 64);
             if (mid && below >= first && below < first + per_pass) res = v;
@@ -1245,7 +1326,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint8_t* np = ns >= 0 ? reinterpret_cast<const uint8_t*>(uniform64(shfl64(sp, ns))) : p + (l - 64u);
         const uint64_t nl = ns >= 0 ? uniform64(shfl64(sl, ns)) : 64u;
         WaveHead nxt;
-        const uint32_t r = wave_crc(p, l, state, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32, hd, np, nl, nxt);
+        const uint32_t r = wave_crc(p, l, state, L, lane, hd, np, nl, nxt);
         hd = nxt;
         requested = ns;
         if ((int)lane == s) res = r;
@@ -1256,26 +1337,24 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
-    constexpr int kWWords = 4 * 256 * kWaveRepl, kGWords = 4 * 256 * kGroupRepl, kXrWords = 4 * 256 * kXRepl;
-    constexpr int kKWords = 4 * 4 * 256, kT8Words = 256;
-    static_assert((kWWords + kGWords + kXrWords + kKWords + kT8Words) * 4 <= 160 * 1024, "LDS");
-    __shared__ uint32_t lds[kWWords + kGWords + kXrWords + kKWords + kT8Words];  // 153 of 160 KiB
-    uint32_t* ldsY = lds;
-    uint32_t* ldsG = lds + kWWords;
-    uint32_t* ldsX = ldsG + kGWords;
-    uint32_t* ldsK = ldsX + kXrWords;
-    uint32_t* ldsT8 = ldsK + kKWords;
+    // all 160 KiB of the CU's LDS: the row-interleaved tables (layout at KiLane), copied
+    // from the image the host built, 16 bytes a lane at a time
+    __shared__ __align__(16) uint32_t lds[kBatchLdsWords];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
-#pragma unroll 16
-    for (int i = tid; i < kWWords; i += kThreads) ldsY[i] = b.tabs->Y1[i >> kWaveReplLog2];
-#pragma unroll 8
-    for (int i = tid; i < kGWords; i += kThreads) ldsG[i] = b.tabs->Y256[i >> kGroupReplLog2];
-#pragma unroll 8
-    for (int i = tid; i < kXrWords; i += kThreads) ldsX[i] = b.tabs->X[i >> kXReplLog2];
-    for (int i = tid; i < kKWords; i += kThreads) ldsK[i] = (&b.tabs->K[0][0])[i];
-    for (int i = tid; i < kT8Words; i += kThreads) ldsT8[i] = b.tabs->T8[i];
+    {
+        const u32x4* img = reinterpret_cast<const u32x4*>(b.tabs->batch_image);
+        static_assert(kBatchLdsWords % (4 * kThreads) == 0, "whole rounds of 16-byte copies");
+        u32x4 t[kBatchLdsWords / (4 * kThreads)];
+#pragma unroll
+        for (int r = 0; r < kBatchLdsWords / (4 * kThreads); ++r) t[r] = img[tid + (uint32_t)(r * kThreads)];
+#pragma unroll
+        for (int r = 0; r < kBatchLdsWords / (4 * kThreads); ++r)
+            reinterpret_cast<u32x4*>(lds)[tid + (uint32_t)(r * kThreads)] = t[r];
+    }
+    // the lookups address LDS absolutely (ki_read): the tables must start at address 0
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsBytes)lds)) != 0u) __builtin_trap();
+    const KiLane L = ki_lane(lane);
     __syncthreads();
 
     const uint32_t W = b.items_per_wave;
@@ -1347,7 +1426,8 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             // memory, no pass of the span code.
             uint32_t r = 0xFFFFFFFFu;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r = table_step_byte(r, (type2 >> (24 - 8 * k)) & 0xffu, ldsT8);
+            for (int k = 0; k < 4; ++k)
+                r = ki_step_byte(r, (type2 >> (24 - 8 * k)) & 0xffu, ki_t8(lane));
             r1 = span1 ? r : 0u;
             send_done = true;
         }
@@ -1370,7 +1450,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
                 }
             }
             crc_spans<MODE>(b, slot ? span1 : span0, reinterpret_cast<uint64_t>(sp), sl, i, cont, dlen, may_file,
-                            r, f, ldsY, ldsG, ldsX, ldsK, ldsT8, lane, lane32);
+                            r, f, L, lane);
             if (slot) {
                 r1 = r;
             } else {
