@@ -1224,16 +1224,6 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
 }
 
-// The largest v of the wave, in every lane.
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
 // The spans `slot` of this wave's items: registers over the whole span into `res`
 // (lanes with want == true), except for lanes whose span was filed (`filed`).
 // `may_file`: long spans may go to the piece kernel (primary span only).
@@ -1249,61 +1239,89 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
         const uint32_t r = lane_crc(reinterpret_cast<const uint8_t*>(sp), (uint32_t)sl, state, tiny, lane);
         if (tiny) res = r;
     }
-    // 32 .. 4080 bytes: a group of lanes each -- 2 lanes while no such span of the turn
-    // exceeds 64 bytes (32 spans per pass), 4 up to kGroup4Max (16 per pass), else 8 (8 per pass)
+    // 32 .. 4080 bytes: a group of lanes each.  The spans of the turn are taken in ORDER OF
+    // LENGTH (classes of 64, 128, 256 bytes, then one per 256 bytes; lane order inside a
+    // class) and every pass picks its own shape from the spans it holds: 2 lanes while the
+    // next 32 are all of 64 bytes or less, 4 lanes while the next 16 fit 256, else 8 lanes for
+    // the next 8.  A pass lasts as long as its longest span, so spans of like length belong
+    // together: taken in lane order with ONE shape for the turn (round 2), a turn of mixed
+    // 32..4080-byte spans kept its groups busy little more than half the time, and one long
+    // span made a turn of short ones run 8 to a pass instead of 32.
     const bool mid = want && sl > (uint64_t)kTinyMax && sl <= (uint64_t)kGroupMax;
     const unsigned long long m = __ballot(mid);
     if (m) {
-        // the k-th span of the turn (in lane order) goes to group k: lane `rank` learns
-        // which lane holds it from a permutation that sends every lane id to its rank
-        // (spans first, in order; the other lanes behind them)
+        static_assert(kGroup4Max == 256 && kEndFramedMax == 1024, "the length classes below");
+        constexpr uint32_t kClass64 = 0, kClass128 = 1, kClass256 = 2, kClassEndFramed = 5, kClasses = 18;
+        const uint32_t len32 = (uint32_t)sl;
+        const uint32_t cls = !mid ? 31u : len32 <= 64u ? kClass64 : len32 <= 128u ? kClass128 : 2u + ((len32 - 1u) >> 8);
         const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        // rank of every span in (class, lane) order; lanes without one come behind
         const uint32_t below = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        const uint32_t rank = mid ? below : cnt + (lane - below);
-        const uint32_t holder = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)lane);
-        // the group's shape follows the longest span of the turn (see group_crc)
-        const uint32_t longest = wave_max_u32(mid ? (uint32_t)sl : 0u);
-        const uint32_t lgw = longest <= 64u ? 1u : longest <= (uint32_t)kGroup4Max ? 2u : 3u;  // log2(lanes per group)
-        const uint32_t per_pass = 64u >> lgw;
-        uint32_t first = 0;
-        // two passes at a time while there are two to take
-        // (plain buffers: every end-framed shape; chunk modes: up to 128 bytes, larger pairs
-        // make them spill; the document mode: none, it has no registers for that)
-        for (; MODE != 2 && (longest <= 128u || (MODE == 0 && longest <= (uint32_t)kEndFramedMax)) && first + per_pass < cnt;
-             first += 2u * per_pass) {
-            const uint32_t ia = first + (lane >> lgw), ib = ia + per_pass;
-            const bool ona = ia < cnt, onb = ib < cnt;
-            const int ma = (int)__shfl(holder, (int)(ona ? ia : 0u), 64), mb = (int)__shfl(holder, (int)(onb ? ib : 0u), 64);
-            const uint8_t* pa = reinterpret_cast<const uint8_t*>(shfl64(sp, ma));
-            const uint8_t* pb = reinterpret_cast<const uint8_t*>(shfl64(sp, mb));
-            const uint32_t la = __shfl((uint32_t)sl, ma, 64), lb = __shfl((uint32_t)sl, mb, 64);
-            // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
-            // inlined as well makes the document mode spill)
-            const uint64_t rr = longest <= 64u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                : longest <= 128u ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                : longest <= (uint32_t)kGroup4Max
-                                    ? group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                    : group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane);
-            const uint32_t k = below - first;  // which of the 2 * per_pass spans, for the lanes it concerns
-            const int src = (int)((k & (per_pass - 1u)) << lgw);
-            const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
-            if (mid && below >= first && k < 2u * per_pass) res = k < per_pass ? va : vb;
+        uint32_t rank = mid ? below : cnt + (lane - below);
+        const uint32_t cls0 = (uint32_t)__builtin_amdgcn_readlane((int)cls, __builtin_ctzll(m));
+        if (__ballot(cls == cls0) != m) {  // more than one class in the turn (else lane order is class order)
+            uint32_t base = 0;
+            for (uint32_t v = 0; v < kClasses; ++v) {
+                const unsigned long long mv = __ballot(cls == v);
+                if (!mv) continue;
+                const uint32_t within =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+                rank = cls == v ? base + within : rank;
+                base += (uint32_t)__builtin_popcountll(mv);
+            }
         }
-        for (; first < cnt; first += per_pass) {
-            const uint32_t idx = first + (lane >> lgw);
-            const bool on = idx < cnt;
-            const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
-            const uint32_t l = __shfl((uint32_t)sl, mine, 64);
-            uint32_t r;
-            if (longest <= 64u) r = group_crc<2, 2, true>(p, l, state, on, L, lane);
-            else if (longest <= 128u) r = group_crc<4, 2, true>(p, l, state, on, L, lane);
-            else if (longest <= (uint32_t)kGroup4Max) r = group_crc<4, 4, true>(p, l, state, on, L, lane);
-            else if (longest <= (uint32_t)kEndFramedMax) r = group_crc<8, 2, true>(p, l, state, on, L, lane);
-            else r = group_crc<8, 2, false>(p, l, state, on, L, lane);
-            // back to the lanes that hold the spans: rank - first is the group that did it
-            const uint32_t v = __shfl(r, (int)(((below - first) & (per_pass - 1u)) << lgw), 64);
-            if (mid && below >= first && below < first + per_pass) res = v;
+        // lane r learns which lane holds the span of rank r, and that span's class
+        const uint32_t holder = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)lane);
+        const uint32_t cls_at = __shfl(cls, (int)holder, 64);
+        auto class_at = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)cls_at, (int)(r < cnt ? r : cnt - 1u)); };
+        for (uint32_t first = 0; first < cnt;) {
+            // this pass: its shape from the longest class among the spans it would hold
+            const uint32_t c32 = class_at(first + 31u), c16 = class_at(first + 15u), c8 = class_at(first + 7u);
+            const uint32_t lgw = c32 == kClass64 ? 1u : c16 <= kClass256 ? 2u : 3u;  // log2(lanes per group)
+            const uint32_t per_pass = 64u >> lgw;
+            const uint32_t top = lgw == 1u ? c32 : lgw == 2u ? c16 : c8;             // longest class of the pass
+            // two passes at a time while the next one has the same shape
+            // (plain buffers: every end-framed shape; chunk modes: up to 128 bytes, larger pairs
+            // make them spill; the document mode: none, it has no registers for that)
+            const uint32_t top2 = class_at(first + 2u * per_pass - 1u);  // >= top: the spans are in class order
+            const bool same2 = lgw == 1u ? top2 == kClass64 : lgw == 2u ? top2 <= kClass256 : top2 <= kClassEndFramed;
+            const bool pair = MODE != 2 && first + per_pass < cnt && same2 &&
+                              (top2 <= kClass128 || (MODE == 0 && top2 <= kClassEndFramed));
+            if (pair) {
+                const uint32_t ia = first + (lane >> lgw), ib = ia + per_pass;
+                const bool ona = ia < cnt, onb = ib < cnt;
+                const int ma = (int)__shfl(holder, (int)(ona ? ia : 0u), 64), mb = (int)__shfl(holder, (int)(onb ? ib : 0u), 64);
+                const uint8_t* pa = reinterpret_cast<const uint8_t*>(shfl64(sp, ma));
+                const uint8_t* pb = reinterpret_cast<const uint8_t*>(shfl64(sp, mb));
+                const uint32_t la = __shfl(len32, ma, 64), lb = __shfl(len32, mb, 64);
+                // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
+                // inlined as well makes the document mode spill)
+                const uint64_t rr = lgw == 1u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
+                                    : lgw == 3u ? group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
+                                    : top2 <= kClass128 ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
+                                                        : group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, L, lane);
+                const uint32_t k = rank - first;  // which of the 2 * per_pass spans, for the lanes it concerns
+                const int src = (int)((k & (per_pass - 1u)) << lgw);
+                const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
+                if (mid && rank >= first && k < 2u * per_pass) res = k < per_pass ? va : vb;
+                first += 2u * per_pass;
+            } else {
+                const uint32_t idx = first + (lane >> lgw);
+                const bool on = idx < cnt;
+                const int mine = (int)__shfl(holder, (int)(on ? idx : 0u), 64);
+                const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
+                const uint32_t l = __shfl(len32, mine, 64);
+                uint32_t r;
+                if (lgw == 1u) r = group_crc<2, 2, true>(p, l, state, on, L, lane);
+                else if (lgw == 2u && top <= kClass128) r = group_crc<4, 2, true>(p, l, state, on, L, lane);
+                else if (lgw == 2u) r = group_crc<4, 4, true>(p, l, state, on, L, lane);
+                else if (top <= kClassEndFramed) r = group_crc<8, 2, true>(p, l, state, on, L, lane);
+                else r = group_crc<8, 2, false>(p, l, state, on, L, lane);
+                // back to the lanes that hold the spans: rank - first is the group that did it
+                const uint32_t v = __shfl(r, (int)(((rank - first) & (per_pass - 1u)) << lgw), 64);
+                if (mid && rank >= first && rank < first + per_pass) res = v;
+                first += per_pass;
+            }
         }
     }
     // longer: the whole wave, one at a time -- or filed for the piece kernel
