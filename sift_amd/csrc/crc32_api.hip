@@ -339,11 +339,14 @@ void build_tables(DeviceTables* t) {
             for (uint32_t c = 0; c < 8; ++c) {
                 t->batch_image[b * 64 + 4 * c + k] = t->Y256[k * 256 + b];             // block 0: G
                 t->batch_image[b * 64 + 32 + 4 * c + k] = t->X[k * 256 + b];           //          X
-                t->batch_image[32768 + b * 32 + 4 * c + k] = t->Y1[k * 256 + b];       // block 2: Y1
+                t->batch_image[16384 + b * 64 + 4 * c + k] = t->K[2][k * 256 + b];     // block 1: K2
             }
-            for (uint32_t j = 0; j < 4; ++j)
-                for (uint32_t c = 0; c < 4; ++c)
-                    t->batch_image[16384 + b * 64 + 16 * j + 4 * c + k] = t->K[j][k * 256 + b];  // block 1: K0..K3
+            for (uint32_t c = 0; c < 8; ++c) t->batch_image[32768 + b * 32 + 4 * c + k] = t->Y1[k * 256 + b];  // block 2: Y1
+            for (uint32_t c = 0; c < 4; ++c) t->batch_image[16384 + b * 64 + 32 + 4 * c + k] = t->K[1][k * 256 + b];  // K1
+            for (uint32_t c = 0; c < 2; ++c) {
+                t->batch_image[16384 + b * 64 + 48 + 4 * c + k] = t->K[0][k * 256 + b];  // K0
+                t->batch_image[16384 + b * 64 + 56 + 4 * c + k] = t->K[3][k * 256 + b];  // K3
+            }
         }
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;

@@ -39,22 +39,28 @@ constexpr int kYWords = 4 * 256 * kRepl;  // 32768 words = 128 KiB
 constexpr int kXWords = 4 * 256;          // 4 KiB, not replicated (used 16x per lane per launch)
 constexpr int kWaves = kThreads / 64;
 
+// a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96: gfx950 has no v_xor3).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 // acc * y: four lookups in the bank-replicated table.  Entry (k, b) for bank
 // r lives at word ((k*256 + b) * 32 + r); lane l uses r = l & 31, so the 32
 // lanes of a ds_read_b32 lane group hit 32 different banks whatever b is.
-__device__ __forceinline__ uint32_t mul_y(uint32_t a, const uint32_t* ldsY, uint32_t lane32) {
-    constexpr int T = 256 * kRepl;  // words per table
+// acc * y + w, the Horner step of one word: the fifth term rides in the second three-way XOR
+__device__ __forceinline__ uint32_t mul_y_add(uint32_t a, uint32_t w, const uint32_t* ldsY, uint32_t lane32) {
+    constexpr int T = 256 * kRepl;
     uint32_t i0 = ((a & 0xffu) << kReplLog2) + lane32;
     uint32_t i1 = (((a >> 8) & 0xffu) << kReplLog2) + lane32;
     uint32_t i2 = (((a >> 16) & 0xffu) << kReplLog2) + lane32;
     uint32_t i3 = ((a >> 24) << kReplLog2) + lane32;
-    return ldsY[i0] ^ ldsY[T + i1] ^ ldsY[2 * T + i2] ^ ldsY[3 * T + i3];
+    return xor3(xor3(ldsY[i0], ldsY[T + i1], ldsY[2 * T + i2]), ldsY[3 * T + i3], w);
 }
 
 // v * x^32: the reference's table step applied to four bytes at once.
 template <typename P>
 __device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
-    return ldsX[v & 0xffu] ^ ldsX[256 + ((v >> 8) & 0xffu)] ^ ldsX[512 + ((v >> 16) & 0xffu)] ^
+    return xor3(ldsX[v & 0xffu], ldsX[256 + ((v >> 8) & 0xffu)], ldsX[512 + ((v >> 16) & 0xffu)]) ^
            ldsX[768 + (v >> 24)];
 }
 
@@ -96,9 +102,13 @@ __device__ __forceinline__ uint32_t table_step_byte(uint32_t c, uint32_t byte, P
 // l + 16 share).  And with rows of 256 bytes the whole address is ONE v_perm_b32: byte 1 =
 // the operand's byte k_j, byte 0 = the lane's offset in the row, byte 2 = the 64 KiB block:
 //     block 0  [0, 64 K)      rows of 256 B:  G = x^(8*256) C = 8 | X = x^32 C = 8
-//     block 1  [64 K, 128 K)  rows of 256 B:  K0 | K1 | K2 | K3 (x^(128 * 2^j)), C = 4 each
-//     block 2  [128 K, 160 K) rows of 128 B:  Y1 = x^(8*1024) C = 8 (the wave path: its
-//                                             address is the permute shifted right by one)
+//     block 1  [64 K, 128 K)  rows of 256 B:  K2 = x^(128*4) C = 8 | K1 = x^(128*2) C = 4 |
+//                                             K0 = x^128 C = 2 | K3 = x^(128*8) C = 2
+//     block 2  [128 K, 160 K) rows of 128 B:  Y1 = x^(8*1024) C = 8 (the wave path; the address is
+//                                             the permute of doubled offsets shifted right by one)
+// (K2 is the 4-lane shapes' chain step, 48 lookups a pass at 256 bytes, K1 the 2-lane
+// shape's; K0 and K3 are used 4 and at most 16 times a pass.  With Y1 at C = 4 to make room
+// for them, 16 KiB items were 9 % slower.)
 // The reference's own CRC_TABLE (crc.rs:2-20) is X's k = 3 slice: (b << 24) * x^32 = b * x^8.
 // The image is built on the host (DeviceTables::batch_image) and copied in 16 bytes a lane.
 // The tables start at LDS address 0 (the kernel's one __shared__ array; checked in its
@@ -130,7 +140,6 @@ __device__ __forceinline__ KiLane ki_lane(uint32_t lane) {
     return L;
 }
 enum : int { kTabG = 0, kTabX = 128 };                                   // block 0, C = 8
-enum : int { kTabK0 = 0, kTabK1 = 64, kTabK2 = 128, kTabK3 = 192 };      // block 1, C = 4
 constexpr int kBatchLdsWords = 40960;                                    // 160 KiB: all of the CU's LDS
 // a * (the table's constant): four lookups, one v_perm_b32 each.  p, q: the lane's row
 // offsets (and block) for the table's geometry; IMM: where the table starts in a row.
@@ -138,24 +147,43 @@ template <int IMM>
 __device__ __forceinline__ uint32_t ki_mul(uint32_t a, const KiLane& L, uint32_t p, uint32_t q) {
     const uint32_t a0 = __builtin_amdgcn_perm(a, p, L.sel[0]), a1 = __builtin_amdgcn_perm(a, p, L.sel[1]);
     const uint32_t a2 = __builtin_amdgcn_perm(a, q, L.sel[2]), a3 = __builtin_amdgcn_perm(a, q, L.sel[3]);
-    return ki_read<IMM>(a0) ^ ki_read<IMM>(a1) ^ ki_read<IMM>(a2) ^ ki_read<IMM>(a3);
+    return xor3(ki_read<IMM>(a0), ki_read<IMM>(a1), ki_read<IMM>(a2)) ^ ki_read<IMM>(a3);
+}
+// a * (the table's constant) + w: the fifth term rides in the second three-way XOR
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul_add(uint32_t a, uint32_t w, const KiLane& L, uint32_t p, uint32_t q) {
+    const uint32_t a0 = __builtin_amdgcn_perm(a, p, L.sel[0]), a1 = __builtin_amdgcn_perm(a, p, L.sel[1]);
+    const uint32_t a2 = __builtin_amdgcn_perm(a, q, L.sel[2]), a3 = __builtin_amdgcn_perm(a, q, L.sel[3]);
+    return xor3(xor3(ki_read<IMM>(a0), ki_read<IMM>(a1), ki_read<IMM>(a2)), ki_read<IMM>(a3), w);
 }
 template <int IMM>
 __device__ __forceinline__ uint32_t ki_mul8(uint32_t a, const KiLane& L) {  // G, X
     return ki_mul<IMM>(a, L, L.p8, L.q8);
 }
-// the C = 4 rows of block 1: the same offsets without the copy's top bit, block byte 1
-__device__ __forceinline__ uint32_t ki_p4(uint32_t p8) { return (p8 & 0x3f3fu) | 0x10000u; }
-template <int IMM>
-__device__ __forceinline__ uint32_t ki_mul4(uint32_t a, const KiLane& L, uint32_t p4, uint32_t q4) {
-    return ki_mul<IMM>(a, L, p4, q4);
-}
-// block 2 (rows of 128 bytes): the permute of doubled offsets with block byte 4, halved
+// block 2 (rows of 128 bytes, C = 8): the permute of doubled offsets with block byte 4, halved
 __device__ __forceinline__ uint32_t ki_py(uint32_t p8) { return (p8 << 1) | 0x40000u; }
-__device__ __forceinline__ uint32_t ki_muly(uint32_t a, const KiLane& L, uint32_t py, uint32_t qy) {
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul2(uint32_t a, const KiLane& L, uint32_t py, uint32_t qy) {
     const uint32_t a0 = __builtin_amdgcn_perm(a, py, L.sel[0]) >> 1, a1 = __builtin_amdgcn_perm(a, py, L.sel[1]) >> 1;
     const uint32_t a2 = __builtin_amdgcn_perm(a, qy, L.sel[2]) >> 1, a3 = __builtin_amdgcn_perm(a, qy, L.sel[3]) >> 1;
-    return ki_read<0>(a0) ^ ki_read<0>(a1) ^ ki_read<0>(a2) ^ ki_read<0>(a3);
+    return xor3(ki_read<IMM>(a0), ki_read<IMM>(a1), ki_read<IMM>(a2)) ^ ki_read<IMM>(a3);
+}
+template <int IMM>
+__device__ __forceinline__ uint32_t ki_mul2_add(uint32_t a, uint32_t w, const KiLane& L, uint32_t py, uint32_t qy) {
+    const uint32_t a0 = __builtin_amdgcn_perm(a, py, L.sel[0]) >> 1, a1 = __builtin_amdgcn_perm(a, py, L.sel[1]) >> 1;
+    const uint32_t a2 = __builtin_amdgcn_perm(a, qy, L.sel[2]) >> 1, a3 = __builtin_amdgcn_perm(a, qy, L.sel[3]) >> 1;
+    return xor3(xor3(ki_read<IMM>(a0), ki_read<IMM>(a1), ki_read<IMM>(a2)), ki_read<IMM>(a3), w);
+}
+__device__ __forceinline__ uint32_t ki_muly_add(uint32_t a, uint32_t w, const KiLane& L, uint32_t py, uint32_t qy) {
+    return ki_mul2_add<0>(a, w, L, py, qy);
+}
+// a * x^(128 * 2^J) + w: the lane-join / chain-join tables, wherever each one lives
+template <int J>
+__device__ __forceinline__ uint32_t ki_mulK_add(uint32_t a, uint32_t w, const KiLane& L) {
+    static_assert(J >= 0 && J <= 3, "K0..K3");
+    if constexpr (J == 2) return ki_mul_add<0>(a, w, L, L.p8 | 0x10000u, L.q8 | 0x10000u);
+    else if constexpr (J == 1) return ki_mul_add<128>(a, w, L, (L.p8 & 0x3f3fu) | 0x10000u, (L.q8 & 0x3f3fu) | 0x10000u);
+    else return ki_mul_add<(J == 0 ? 192 : 224)>(a, w, L, (L.p8 & 0x1f1fu) | 0x10000u, (L.q8 & 0x1f1fu) | 0x10000u);
 }
 // One byte of the reference's recurrence WITH its table (crc.rs:31), the table being X's
 // k = 3 slice; t8 = the lane's offset of such an entry in a row (ki_t8).
@@ -173,7 +201,7 @@ __device__ __forceinline__ void horner_step(u32x4& acc, const u32x4 w, const uin
                                             uint32_t lane32) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        acc[c] = (c < SIFT_ABLATE_WORDS ? mul_y(acc[c], ldsY, lane32) : acc[c]) ^ w[c];
+        acc[c] = c < SIFT_ABLATE_WORDS ? mul_y_add(acc[c], w[c], ldsY, lane32) : acc[c] ^ w[c];
 }
 
 // A 1024-entry table into LDS with every entry copied kRepl times in a row
@@ -715,7 +743,7 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     const uint32_t py = ki_py(L.p8), qy = ki_py(L.q8);  // the wave table's rows (block 2)
     auto horner_y = [&](u32x4& a, const u32x4 w) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[c] = ki_muly(a[c], L, py, qy) ^ w[c];
+        for (int c = 0; c < 4; ++c) a[c] = ki_muly_add(a[c], w[c], L, py, qy);
     };
     const uint64_t addr = reinterpret_cast<uint64_t>(ptr);
     const uint64_t v0 = addr >> 4, v1 = (addr + len) >> 4;
@@ -783,13 +811,12 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
     // place, x^(128 * (63 - lane)), in 32 shift-and-xor steps: some 220 instructions a
     // span against 90 here.  The time per span did not change -- this path waits for
     // memory -- but the kernel needs 9-15 registers fewer and no longer spills.)
-    const uint32_t p4 = ki_p4(L.p8), q4 = ki_p4(L.q8);
-    r = ki_mul4<kTabK0>(r, L, p4, q4) ^ __shfl_xor(r, 1, 64);
-    r = ki_mul4<kTabK1>(r, L, p4, q4) ^ __shfl_xor(r, 2, 64);
-    r = ki_mul4<kTabK2>(r, L, p4, q4) ^ __shfl_xor(r, 4, 64);
-    r = ki_mul4<kTabK3>(r, L, p4, q4) ^ __shfl_xor(r, 8, 64);
-    r = ki_mul8<kTabG>(r, L) ^ __shfl_xor(r, 16, 64);
-    r = ki_mul8<kTabG>(ki_mul8<kTabG>(r, L), L) ^ __shfl_xor(r, 32, 64);
+    r = ki_mulK_add<0>(r, __shfl_xor(r, 1, 64), L);
+    r = ki_mulK_add<1>(r, __shfl_xor(r, 2, 64), L);
+    r = ki_mulK_add<2>(r, __shfl_xor(r, 4, 64), L);
+    r = ki_mulK_add<3>(r, __shfl_xor(r, 8, 64), L);
+    r = ki_mul_add<kTabG>(r, __shfl_xor(r, 16, 64), L, L.p8, L.q8);
+    r = ki_mul_add<kTabG>(ki_mul8<kTabG>(r, L), __shfl_xor(r, 32, 64), L, L.p8, L.q8);
     r = __shfl(r, 0, 64);
     // trailing bytes: every lane walks them alike (no divergence, no broadcast)
     const uint32_t t8 = ki_t8(lane);
@@ -870,7 +897,6 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
     typedef __attribute__((address_space(1))) const u32x4_u* GlobalVecU;
     typedef __attribute__((address_space(1))) const u32x4* GlobalVec;
     const uint32_t lg = lane & (uint32_t)(GW - 1);
-    const uint32_t p4 = ki_p4(L.p8), q4 = ki_p4(L.q8);  // rows of the lane-join tables (block 1)
     // Two framings.  ENDF: the span is framed from its END: vector v covers the 16 bytes
     // that end 16 * (nvec - 1 - v) bytes before the span's end, whatever their address (the
     // hardware takes 16-byte loads at any byte address; off a 4-byte boundary they stream
@@ -983,10 +1009,10 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
                 for (int c = 0; c < NCH; ++c) {
                     if (ha) {  // two words at a time: half the lookups in flight, half the registers
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) ch[c][k] = ki_mul8<kTabG>(ch[c][k], L) ^ w[c][k];
+                        for (int k = 0; k < 2; ++k) ch[c][k] = ki_mul_add<kTabG>(ch[c][k], w[c][k], L, L.p8, L.q8);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 2; k < 4; ++k) ch[c][k] = ki_mul8<kTabG>(ch[c][k], L) ^ w[c][k];
+                        for (int k = 2; k < 4; ++k) ch[c][k] = ki_mul_add<kTabG>(ch[c][k], w[c][k], L, L.p8, L.q8);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1001,10 +1027,11 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
         for (int c = NCH - 2; c >= 0; --c) {
             if (__any(ntile > c + 1)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = ki_mul4<64 * LG>(acc[k], L, p4, q4);
-            }
+                for (int k = 0; k < 4; ++k) acc[k] = ki_mulK_add<LG>(acc[k], ch[c][k], L);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
+                for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
+            }
         }
     }
     // the lane's four words, then the GW lanes joined pairwise: at step j the
@@ -1017,9 +1044,9 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
     uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) r = ki_mul8<kTabX>(r ^ acc[c], L);
-    r = ki_mul4<kTabK0>(r, L, p4, q4) ^ __shfl_xor(r, 1, 64);
-    if constexpr (LG > 1) r = ki_mul4<kTabK1>(r, L, p4, q4) ^ __shfl_xor(r, 2, 64);
-    if constexpr (LG > 2) r = ki_mul4<kTabK2>(r, L, p4, q4) ^ __shfl_xor(r, 4, 64);
+    r = ki_mulK_add<0>(r, __shfl_xor(r, 1, 64), L);
+    if constexpr (LG > 1) r = ki_mulK_add<1>(r, __shfl_xor(r, 2, 64), L);
+    if constexpr (LG > 2) r = ki_mulK_add<2>(r, __shfl_xor(r, 4, 64), L);
     // trailing bytes, with the reference's own table; only lane 0 of a group holds a
     // meaningful register, the others walk along
     if constexpr (!ENDF) {
