@@ -308,6 +308,8 @@ void build_tables(DeviceTables* t) {
             t->Y[k * 256 + b] = gf2_mulmod(b << (8 * k), y);
             t->X[k * 256 + b] = gf2_mulmod(b << (8 * k), x32);
         }
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t b = 0; b < 256; ++b) t->Yt[4 * b + k] = t->Y[k * 256 + b];
     const uint32_t y1 = gf2_xpow(x2n(), 8ull * 1024);
     for (int k = 0; k < 4; ++k)
         for (uint32_t b = 0; b < 256; ++b) t->Y1[k * 256 + b] = gf2_mulmod(b << (8 * k), y1);

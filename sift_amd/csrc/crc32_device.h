@@ -67,6 +67,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Constant tables, built on the host once per device (crc32_api.hip).
 struct DeviceTables {
     uint32_t Y[4 * 256];     // Y[k*256+b] = (b << 8k) * x^(8*kTileBytes) mod P
+    __attribute__((aligned(16))) uint32_t Yt[256 * 4];  // the same by byte value: Yt[4b + k] = Y[k*256+b] (how the kernels' LDS rows want it)
     uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)

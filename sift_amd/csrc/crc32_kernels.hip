@@ -35,57 +35,13 @@ namespace sift {
 
 namespace {
 
-constexpr int kYWords = 4 * 256 * kRepl;  // 32768 words = 128 KiB
+constexpr int kYWords = 256 * 64;          // the y table by byte value in rows of 256 B: 64 KiB (half of each row in use)
 constexpr int kXWords = 4 * 256;          // 4 KiB, not replicated (used 16x per lane per launch)
 constexpr int kWaves = kThreads / 64;
 
 // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96: gfx950 has no v_xor3).
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-}
-
-// acc * y: four lookups in the bank-replicated table.  Entry (k, b) for bank
-// r lives at word ((k*256 + b) * 32 + r); lane l uses r = l & 31, so the 32
-// lanes of a ds_read_b32 lane group hit 32 different banks whatever b is.
-// acc * y + w, the Horner step of one word: the fifth term rides in the second three-way XOR
-__device__ __forceinline__ uint32_t mul_y_add(uint32_t a, uint32_t w, const uint32_t* ldsY, uint32_t lane32) {
-    constexpr int T = 256 * kRepl;
-    uint32_t i0 = ((a & 0xffu) << kReplLog2) + lane32;
-    uint32_t i1 = (((a >> 8) & 0xffu) << kReplLog2) + lane32;
-    uint32_t i2 = (((a >> 16) & 0xffu) << kReplLog2) + lane32;
-    uint32_t i3 = ((a >> 24) << kReplLog2) + lane32;
-    return xor3(xor3(ldsY[i0], ldsY[T + i1], ldsY[2 * T + i2]), ldsY[3 * T + i3], w);
-}
-
-// v * x^32: the reference's table step applied to four bytes at once.
-template <typename P>
-__device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
-    return xor3(ldsX[v & 0xffu], ldsX[256 + ((v >> 8) & 0xffu)], ldsX[512 + ((v >> 16) & 0xffu)]) ^
-           ldsX[768 + (v >> 24)];
-}
-
-// The same two multiplies from tables with 2^RLOG2 copies of every entry in a row
-// (the batch kernel's): lane-chosen copy `lr` < 2^RLOG2.
-template <int RLOG2, typename P>
-__device__ __forceinline__ uint32_t mul_tab(uint32_t a, P tab, uint32_t lr) {
-    constexpr int T = 256 << RLOG2;  // words per byte-position table
-    const uint32_t i0 = ((a & 0xffu) << RLOG2) + lr;
-    const uint32_t i1 = (((a >> 8) & 0xffu) << RLOG2) + lr;
-    const uint32_t i2 = (((a >> 16) & 0xffu) << RLOG2) + lr;
-    const uint32_t i3 = ((a >> 24) << RLOG2) + lr;
-    return tab[i0] ^ tab[T + i1] ^ tab[2 * T + i2] ^ tab[3 * T + i3];
-}
-template <int RLOG2, typename P>
-__device__ __forceinline__ void horner_tab(u32x4& acc, const u32x4 w, P tab, uint32_t lr) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = mul_tab<RLOG2>(acc[c], tab, lr) ^ w[c];
-}
-
-// One byte of the reference's recurrence WITH its table (crc.rs:31):
-// c = CRC_TABLE[(c ^ byte) & 0xff] ^ (c >> 8).
-template <typename P>
-__device__ __forceinline__ uint32_t table_step_byte(uint32_t c, uint32_t byte, P ldsT8) {
-    return ldsT8[(c ^ byte) & 0xffu] ^ (c >> 8);
 }
 
 // ---------------------------------------------------------------------------
@@ -193,41 +149,65 @@ __device__ __forceinline__ uint32_t ki_step_byte(uint32_t c, uint32_t byte, uint
     return ki_read<kTabX>(at) ^ (c >> 8);
 }
 
+// acc * y + w, the tile and piece kernels' Horner step of one word: the y table sits at
+// the start of LDS in the rows-by-byte-value layout above (8 copies, the first half of
+// each 256-byte row), so a lookup is one v_perm_b32 and a conflict-free ds_read_b32.
+// (Until round 3: [k][b][32 copies], 128 KiB, a byte extract and a shift-add per lookup.)
+__device__ __forceinline__ uint32_t mul_y_add(uint32_t a, uint32_t w, const KiLane& L) {
+    return ki_mul_add<0>(a, w, L, L.p8, L.q8);
+}
+
+// v * x^32: the reference's table step applied to four bytes at once.
+template <typename P>
+__device__ __forceinline__ uint32_t mul_x32(uint32_t v, P ldsX) {
+    return xor3(ldsX[v & 0xffu], ldsX[256 + ((v >> 8) & 0xffu)], ldsX[512 + ((v >> 16) & 0xffu)]) ^
+           ldsX[768 + (v >> 24)];
+}
+
+// The same two multiplies from tables with 2^RLOG2 copies of every entry in a row
+// (the batch kernel's): lane-chosen copy `lr` < 2^RLOG2.
+template <int RLOG2, typename P>
+__device__ __forceinline__ uint32_t mul_tab(uint32_t a, P tab, uint32_t lr) {
+    constexpr int T = 256 << RLOG2;  // words per byte-position table
+    const uint32_t i0 = ((a & 0xffu) << RLOG2) + lr;
+    const uint32_t i1 = (((a >> 8) & 0xffu) << RLOG2) + lr;
+    const uint32_t i2 = (((a >> 16) & 0xffu) << RLOG2) + lr;
+    const uint32_t i3 = ((a >> 24) << RLOG2) + lr;
+    return tab[i0] ^ tab[T + i1] ^ tab[2 * T + i2] ^ tab[3 * T + i3];
+}
+template <int RLOG2, typename P>
+__device__ __forceinline__ void horner_tab(u32x4& acc, const u32x4 w, P tab, uint32_t lr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = mul_tab<RLOG2>(acc[c], tab, lr) ^ w[c];
+}
+
+// One byte of the reference's recurrence WITH its table (crc.rs:31):
+// c = CRC_TABLE[(c ^ byte) & 0xff] ^ (c >> 8).
+template <typename P>
+__device__ __forceinline__ uint32_t table_step_byte(uint32_t c, uint32_t byte, P ldsT8) {
+    return ldsT8[(c ^ byte) & 0xffu] ^ (c >> 8);
+}
+
 // One Horner step for a lane's four words: acc <- acc * y + w.
 #ifndef SIFT_ABLATE_WORDS
 #define SIFT_ABLATE_WORDS 4  // timing-only builds thin the step to fewer real multiplies
 #endif
-__device__ __forceinline__ void horner_step(u32x4& acc, const u32x4 w, const uint32_t* ldsY,
-                                            uint32_t lane32) {
+__device__ __forceinline__ void horner_step(u32x4& acc, const u32x4 w, const KiLane& L) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        acc[c] = c < SIFT_ABLATE_WORDS ? mul_y_add(acc[c], w[c], ldsY, lane32) : acc[c] ^ w[c];
+        acc[c] = c < SIFT_ABLATE_WORDS ? mul_y_add(acc[c], w[c], L) : acc[c] ^ w[c];
 }
 
-// A 1024-entry table into LDS with every entry copied kRepl times in a row
-// (mul_y's layout), from four entries per lane in registers: lane t holds
-// entries 4(t>>2) .. +3 (ONE 16-byte load, `stage_fetch`) and writes the quarter
-// (t & 3) of the copies of each with 16-byte stores.  A word-by-word fill takes a
-// lane 32 loads, each 16 cycles of the CU's address unit.
-__device__ __forceinline__ u32x4 stage_fetch(const uint32_t* table, uint32_t q) {
-    return reinterpret_cast<const u32x4*>(table)[q >> 2];
+// The y table into LDS: row b (256 bytes) gets eight copies of the four entries
+// Y[0..3][b] (word 4c + k).  The host keeps the table transposed (DeviceTables::Yt), so a
+// lane fetches the four entries of a row with ONE 16-byte load and stores them as one
+// 16-byte word per copy: 2048 (row, copy) pairs, two a lane at 1024 lanes.
+constexpr int kStagePairs = 256 * 8;
+__device__ __forceinline__ u32x4 stage_fetch(const uint32_t* yt, uint32_t pair) {
+    return reinterpret_cast<const u32x4*>(yt)[pair >> 3];
 }
-__device__ __forceinline__ void stage_store(uint32_t* ldsT, const u32x4 e, uint32_t q) {
-    constexpr int kQuarter = kRepl / 4;  // copies of an entry one lane writes
-    static_assert(kQuarter % 4 == 0 || kQuarter == 2, "SIFT_REPL");
-    const uint32_t quad = q >> 2, part = q & 3u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        uint32_t* dst = ldsT + (quad * 4u + (uint32_t)w) * (uint32_t)kRepl + part * (uint32_t)kQuarter;
-        if constexpr (kQuarter % 4 == 0) {
-            const u32x4 v = {e[w], e[w], e[w], e[w]};
-#pragma unroll
-            for (int r = 0; r < kQuarter / 4; ++r) reinterpret_cast<u32x4*>(dst)[r] = v;
-        } else {
-            dst[0] = e[w];
-            dst[1] = e[w];
-        }
-    }
+__device__ __forceinline__ void stage_store(uint32_t* lds, const u32x4 e, uint32_t pair) {
+    reinterpret_cast<u32x4*>(lds)[(pair >> 3) * 16u + (pair & 7u)] = e;
 }
 
 // A value every lane of the wave agrees on, moved to scalar registers (the
@@ -290,8 +270,9 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     uint32_t* red = ldsX + kXWords;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);  // which table copy this lane reads
-    const uint32_t row32 = tid & 31u;                     // its row in a 32-lane product
+    const KiLane L = ki_lane(tid);      // where this lane's lookups go in the y table's rows
+    if (USE_Y && static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsBytes)lds)) != 0u) __builtin_trap();  // ki_read
+    const uint32_t row32 = tid & 31u;   // its row in a 32-lane product
     const int64_t g = blockIdx.x;
 #if defined(SIFT_TRACE_FINISH)  // timing-only build (tools/trace_groups.py): 100 MHz clock at four points per group
 #define SIFT_TRACE(slot) \
@@ -314,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // return in order, so the tables are staged and the lane's matrix rows built
     // while the first message bytes are still on their way from HBM; asked for
     // after the message, they used to arrive behind it.
-    constexpr int kStageRounds = USE_Y ? (1024 + kThreads - 1) / kThreads : 0;  // 1 at 1024 lanes
+    constexpr int kStageRounds = USE_Y ? (kStagePairs + kThreads - 1) / kThreads : 0;  // 2 at 1024 lanes
     constexpr int kXRounds = (kXWords + kThreads - 1) / kThreads;
     u32x4 ty[kStageRounds > 0 ? kStageRounds : 1];
     uint32_t tx[kXRounds];
@@ -322,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int k = 0; k < kStageRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
-        ty[k] = stage_fetch(a.tabs->Y, q < 1024u ? q : 0u);
+        ty[k] = stage_fetch(a.tabs->Yt, q < (uint32_t)kStagePairs ? q : 0u);
     }
 #endif
 #pragma unroll
@@ -388,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int k = 0; k < kStageRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
-        if (q < 1024u) stage_store(ldsY, ty[k], q);
+        if (q < (uint32_t)kStagePairs) stage_store(ldsY, ty[k], q);
     }
 #endif
 #pragma unroll
@@ -443,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], L);
                 // The batch before must have landed before the next one is asked
                 // for (one batch in flight per wave: two cost 3 % of HBM rate), and
                 // a batch's loads go out back to back.
@@ -460,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], nxt[u][j], ldsY, lane32);
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], nxt[u][j], L);
             }
             if (ntiles >= U) {
 #pragma unroll
@@ -473,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
+                    for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], L);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -482,13 +463,13 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], ldsY, lane32);
+                for (int j = 0; j < kVpl; ++j) horner_step(acc[j], cur[u][j], L);
         }
         while (ntiles > 0) {
 #pragma unroll
             for (int j = 0; j < kVpl; ++j) {
                 const u32x4 w = load_tile(srd, voff, soff + j * kThreads * 16);
-                horner_step(acc[j], w, ldsY, lane32);
+                horner_step(acc[j], w, L);
             }
             soff += kTileBytes;
             --ntiles;
@@ -1726,12 +1707,17 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     // and headers are read.
     static_assert(kXWords == 1024 && kZWords == 1024, "tables of 1024 words");
     constexpr int kRounds = (1024 + kThreads - 1) / kThreads;  // 1 at 1024 lanes
-    u32x4 ty[kRounds];
+    constexpr int kYRounds = (kStagePairs + kThreads - 1) / kThreads;  // 2 at 1024 lanes
+    u32x4 ty[kYRounds];
     uint32_t tx[kRounds], tz[kRounds];
+#pragma unroll
+    for (int k = 0; k < kYRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads);
+        ty[k] = stage_fetch(b.tabs->Yt, q < (uint32_t)kStagePairs ? q : 0u);
+    }
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads) < 1024u ? tid + (uint32_t)(k * kThreads) : 0u;
-        ty[k] = stage_fetch(b.tabs->Y, q);
         tx[k] = b.tabs->X[q];
         tz[k] = (&b.tabs->X2[0][0])[q];
     }
@@ -1754,13 +1740,18 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
         return;
     }
 
-    const uint32_t lane32 = tid & (uint32_t)(kRepl - 1);
+    const KiLane L = ki_lane(tid);
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsBytes)lds)) != 0u) __builtin_trap();  // ki_read
     const uint32_t row32 = tid & 31u;
+#pragma unroll
+    for (int k = 0; k < kYRounds; ++k) {
+        const uint32_t q = tid + (uint32_t)(k * kThreads);
+        if (q < (uint32_t)kStagePairs) stage_store(ldsY, ty[k], q);
+    }
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
         if (q < 1024u) {
-            stage_store(ldsY, ty[k], q);
             ldsX[q] = tx[k];
             ldsZ[q] = tz[k];
         }
@@ -1890,7 +1881,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
 #pragma unroll
                 for (int u = 0; u < U; ++u) nxt[u] = load_tile(srd, voff, soff + u * kTileBytes);
 #pragma unroll
-                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], L);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
@@ -1899,7 +1890,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
                 soff += 2 * U * kTileBytes;
                 ntiles -= 2 * U;
 #pragma unroll
-                for (int u = 0; u < U; ++u) horner_step(acc, nxt[u], ldsY, lane32);
+                for (int u = 0; u < U; ++u) horner_step(acc, nxt[u], L);
             }
             if (ntiles >= U) {
 #pragma unroll
@@ -1907,16 +1898,16 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
                 soff += U * kTileBytes;
                 ntiles -= U;
 #pragma unroll
-                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+                for (int u = 0; u < U; ++u) horner_step(acc, cur[u], L);
 #pragma unroll
                 for (int u = 0; u < U; ++u) cur[u] = nxt[u];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) horner_step(acc, cur[u], ldsY, lane32);
+            for (int u = 0; u < U; ++u) horner_step(acc, cur[u], L);
         }
         while (ntiles > 0) {
             const u32x4 w = load_tile(srd, voff, soff);
-            horner_step(acc, w, ldsY, lane32);
+            horner_step(acc, w, L);
             soff += kTileBytes;
             --ntiles;
         }
