@@ -239,16 +239,52 @@ __device__ __forceinline__ u32x4 mask_head(u32x4 w, uint32_t skip) {
     return w;
 }
 
+// XOR over lanes with data-parallel-primitive modifiers on the XOR itself (a few
+// cycles a step) instead of ds_bpermute shuffles (an LDS round trip a step: the
+// reductions at the end of a call sit on its critical path, some 0.3 us a reduction).
+// After xor_rows16 every lane holds the XOR of its row of 16 lanes.
+__device__ __forceinline__ uint32_t xor_rows16(uint32_t v) {
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);  // row_mirror
+    return v;
+}
+// XOR over each half-wave, in every lane (uniform per half: returned from lane 31 / 63
+// by the caller's choice).  Rows 1 and 3 take in the row before them.
+__device__ __forceinline__ uint32_t half_xor(uint32_t v) {
+    v = xor_rows16(v);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast15 into rows 1, 3
+    return v;  // lanes 16..31 hold the XOR of lanes 0..31, lanes 48..63 that of 32..63
+}
+// XOR over the wave, in every lane.
 __device__ __forceinline__ uint32_t wave_xor(uint32_t r) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) r ^= __shfl_xor(r, off, 64);
-    return r;
+    r = half_xor(r);
+    r ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, true);  // row_bcast31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
 }
 
+__device__ __forceinline__ void store_result(uint32_t r, const FinalArgs& f);
 // Trailing bytes and the store; one lane.  `body` already carries the state.
+// `tailv`: the 16-byte block the trailing bytes lie in, fetched in the prologue (asked for
+// here, byte by byte, they were up to 15 dependent trips to memory at the very end of
+// the call).
+__device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f, u32x4 tailv) {
+    uint32_t r = body;
+    for (uint32_t i = 0; i < f.tail_len; ++i) {
+        r = crc_step_byte(r, tailv[0] & 0xffu);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tailv[c] = (tailv[c] >> 8) | (tailv[c + 1] << 24);
+        tailv[3] >>= 8;
+    }
+    store_result(r, f);
+}
 __device__ __forceinline__ void finish(uint32_t body, const FinalArgs& f) {
     uint32_t r = body;
     for (uint32_t i = 0; i < f.tail_len; ++i) r = crc_step_byte(r, f.tail[i]);
+    store_result(r, f);
+}
+__device__ __forceinline__ void store_result(uint32_t r, const FinalArgs& f) {
     if (f.tag)
         *reinterpret_cast<volatile unsigned long long*>(f.out) =
             ((unsigned long long)f.tag << 32) | (unsigned long long)(r ^ f.xor_out);
@@ -313,6 +349,9 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     }
     uint32_t kb[32];
     kb[0] = a.tabs->Kt[tid];
+    // the block the trailing bytes lie in (16-byte aligned, inside the page of the last
+    // byte), for whichever group turns out to finish the call
+    const u32x4 tailv = *reinterpret_cast<const u32x4*>(f.tail_len ? f.tail : reinterpret_cast<const uint8_t*>(a.vbase));
     __builtin_amdgcn_sched_barrier(0);
 
     // A lane holds kVpl vectors of a tile (vector t + j*kThreads for j < kVpl),
@@ -513,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // Wave 0 finishes the group.
     uint32_t x = wave_xor(tid < (uint32_t)kWaves ? red[tid] : 0u);
     if (a.fuse_final) {  // one group did everything
-        if (tid == 0) finish(x, f);
+        if (tid == 0) finish(x, f, tailv);
         return;
     }
     if (!a.single_launch) {  // two-launch form: raw residue, combine kernel weights it
@@ -532,10 +571,8 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int s = 0; s < kTreeLevels; ++s) {
         if ((h >> s) & 1u) {  // uniform
-            uint32_t t = ((x >> (31u - row32)) & 1u) ? rows[s] : 0u;
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
-            x = t;
+            const uint32_t t = ((x >> (31u - row32)) & 1u) ? rows[s] : 0u;
+            x = (uint32_t)__builtin_amdgcn_readlane((int)half_xor(t), 31);
         }
     }
 #endif
@@ -581,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
             __hip_atomic_fetch_xor(words, ((unsigned long long)full2 << 32) | total, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
-        finish(total, f);
+        finish(total, f, tailv);
     }
 }
 
@@ -1108,10 +1145,8 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
 // half-wave holds row k and contributes it when bit 31-k of x is set; a 5-step
 // butterfly sums the rows.  Every lane of the wave returns the product.
 __device__ __forceinline__ uint32_t mul_rows(uint32_t x, uint32_t row, uint32_t row32) {
-    uint32_t t = ((x >> (31u - row32)) & 1u) ? row : 0u;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) t ^= __shfl_xor(t, off, 64);
-    return t;
+    const uint32_t t = ((x >> (31u - row32)) & 1u) ? row : 0u;
+    return (uint32_t)__builtin_amdgcn_readlane((int)half_xor(t), 31);
 }
 
 // Level and piece count of a span whose whole vectors cover `body` bytes.
