@@ -309,7 +309,10 @@ void build_tables(DeviceTables* t) {
             t->X[k * 256 + b] = gf2_mulmod(b << (8 * k), x32);
         }
     for (int k = 0; k < 4; ++k)
-        for (uint32_t b = 0; b < 256; ++b) t->Yt[4 * b + k] = t->Y[k * 256 + b];
+        for (uint32_t b = 0; b < 256; ++b) {
+            t->Yt[4 * b + k] = t->Y[k * 256 + b];
+            t->Xt[4 * b + k] = t->X[k * 256 + b];
+        }
     const uint32_t y1 = gf2_xpow(x2n(), 8ull * 1024);
     for (int k = 0; k < 4; ++k)
         for (uint32_t b = 0; b < 256; ++b) t->Y1[k * 256 + b] = gf2_mulmod(b << (8 * k), y1);
@@ -354,6 +357,11 @@ void build_tables(DeviceTables* t) {
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {
         t->Kt[tdx] = p;
+        uint32_t r = p;
+        for (int i = 0; i < 32; ++i) {
+            t->KtRows[32 * tdx + i] = r;
+            r = gf2_mulx(r);
+        }
         p = gf2_mulmod(p, x128);
     }
 }

@@ -30,13 +30,15 @@
 #ifndef SIFT_LOAD_AUX
 #define SIFT_LOAD_AUX 2  // nt
 #endif
+#ifndef SIFT_KB_LOAD
+#define SIFT_KB_LOAD 0  // 1: the lane's 32 matrix rows come from a table instead of being computed (A/B: 2.5 us slower a call)
+#endif
 
 namespace sift {
 
 namespace {
 
 constexpr int kYWords = 256 * 64;          // the y table by byte value in rows of 256 B: 64 KiB (half of each row in use)
-constexpr int kXWords = 4 * 256;          // 4 KiB, not replicated (used 16x per lane per launch)
 constexpr int kWaves = kThreads / 64;
 
 // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96: gfx950 has no v_xor3).
@@ -206,8 +208,8 @@ constexpr int kStagePairs = 256 * 8;
 __device__ __forceinline__ u32x4 stage_fetch(const uint32_t* yt, uint32_t pair) {
     return reinterpret_cast<const u32x4*>(yt)[pair >> 3];
 }
-__device__ __forceinline__ void stage_store(uint32_t* lds, const u32x4 e, uint32_t pair) {
-    reinterpret_cast<u32x4*>(lds)[(pair >> 3) * 16u + (pair & 7u)] = e;
+__device__ __forceinline__ void stage_store(uint32_t* lds, const u32x4 e, uint32_t pair, uint32_t half = 0) {
+    reinterpret_cast<u32x4*>(lds)[(pair >> 3) * 16u + half * 8u + (pair & 7u)] = e;  // half 1: the rows' second 128 bytes
 }
 
 // A value every lane of the wave agrees on, moved to scalar registers (the
@@ -297,17 +299,17 @@ __device__ __forceinline__ void store_result(uint32_t r, const FinalArgs& f) {
 template <bool USE_Y>
 __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, FinalArgs f,
                                                                CombineMats m) {
-    // One array (see the guide's second-__shared__-object trap); the one-tile
-    // variant needs no y table and so leaves the CU's LDS to other workgroups.
-    constexpr int kYUsed = USE_Y ? kYWords : 0;
-    __shared__ __align__(16) uint32_t lds[kYUsed + kXWords + kWaves];
+    // One array (see the guide's second-__shared__-object trap): 256 rows of 256 bytes,
+    // the y table in their first halves (not staged by the one-tile variant), the x^32
+    // table in their second halves (8 copies each: conflict-free lookups; with one copy of
+    // x^32 the 16 lookups a lane makes at the end cost the call half a microsecond).
+    __shared__ __align__(16) uint32_t lds[kYWords + kWaves];
     uint32_t* ldsY = lds;
-    uint32_t* ldsX = lds + kYUsed;
-    uint32_t* red = ldsX + kXWords;
+    uint32_t* red = lds + kYWords;
 
     const uint32_t tid = threadIdx.x;
     const KiLane L = ki_lane(tid);      // where this lane's lookups go in the y table's rows
-    if (USE_Y && static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsBytes)lds)) != 0u) __builtin_trap();  // ki_read
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsBytes)lds)) != 0u) __builtin_trap();  // ki_read
     const uint32_t row32 = tid & 31u;   // its row in a 32-lane product
     const int64_t g = blockIdx.x;
 #if defined(SIFT_TRACE_FINISH)  // timing-only build (tools/trace_groups.py): 100 MHz clock at four points per group
@@ -332,9 +334,9 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // while the first message bytes are still on their way from HBM; asked for
     // after the message, they used to arrive behind it.
     constexpr int kStageRounds = USE_Y ? (kStagePairs + kThreads - 1) / kThreads : 0;  // 2 at 1024 lanes
-    constexpr int kXRounds = (kXWords + kThreads - 1) / kThreads;
+    constexpr int kXRounds = (kStagePairs + kThreads - 1) / kThreads;
     u32x4 ty[kStageRounds > 0 ? kStageRounds : 1];
-    uint32_t tx[kXRounds];
+    u32x4 tx[kXRounds];
 #if !defined(SIFT_ABLATE_FILL)
 #pragma unroll
     for (int k = 0; k < kStageRounds; ++k) {
@@ -345,10 +347,12 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int k = 0; k < kXRounds; ++k) {
         const uint32_t i = tid + (uint32_t)(k * kThreads);
-        tx[k] = a.tabs->X[i < (uint32_t)kXWords ? i : 0u];
+        tx[k] = stage_fetch(a.tabs->Xt, i < (uint32_t)kStagePairs ? i : 0u);
     }
     uint32_t kb[32];
+#if !SIFT_KB_LOAD
     kb[0] = a.tabs->Kt[tid];
+#endif
     // the block the trailing bytes lie in (16-byte aligned, inside the page of the last
     // byte), for whichever group turns out to finish the call
     const u32x4 tailv = *reinterpret_cast<const u32x4*>(f.tail_len ? f.tail : reinterpret_cast<const uint8_t*>(a.vbase));
@@ -401,6 +405,23 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         soff += U * kTileBytes;
         ntiles -= U;
     }
+#if SIFT_KB_LOAD
+    // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its multiplication
+    // matrix (3 instructions a bit at the end instead of 7): asked for BEHIND the first
+    // message vectors -- they are not needed before the end of the call -- from a table of
+    // all 1024 x 32 rows.  (Until round 3 each lane computed its rows from Kt[tid] in the
+    // prologue: 124 dependent instructions a lane, 0.8 us of a CU's vector issue while the
+    // tables wait to be staged.)
+    {
+        const u32x4* rows = reinterpret_cast<const u32x4*>(a.tabs->KtRows) + tid * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4 v = rows[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kb[4 * i + j] = v[j];
+        }
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
     // Tables -> LDS.
@@ -414,16 +435,18 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
 #pragma unroll
     for (int k = 0; k < kXRounds; ++k) {
         const uint32_t i = tid + (uint32_t)(k * kThreads);
-        if (i < (uint32_t)kXWords) ldsX[i] = tx[k];
+        if (i < (uint32_t)kStagePairs) stage_store(lds, tx[k], i, 1u);
     }
     // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its
     // multiplication matrix: computed here, while the first loads are in flight
     // and the VALU is idle, and kept in registers through the main loop, so that
     // the multiply at the end is 3 instructions per bit instead of 7.
+#if !SIFT_KB_LOAD
 #pragma unroll
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));  // pin: do not sink past the loop
+#endif
     __syncthreads();
     SIFT_TRACE(1);
 
@@ -531,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         }
         uint32_t rj = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rj = mul_x32(rj ^ acc[j][c], ldsX);
+        for (int c = 0; c < 4; ++c) rj = ki_mul8<kTabX>(rj ^ acc[j][c], L);
         r ^= rj;
     }
 #if defined(SIFT_ABLATE_MULMOD)  // timing-only build (tools/): wrong results by design
@@ -1727,10 +1750,9 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
                                                                 std::conditional_t<INL, InlineDesc, NoInline> d) {
     constexpr int kZWords = 32 * 32;
     constexpr int kPlanWords = PLAN ? (int)(kPlanMax * sizeof(CutRecord) / 4 + kPlanMax + 16) : 0;
-    __shared__ __align__(16) uint32_t lds[kYWords + kXWords + kZWords + 2 * kWaves + kPlanWords];
+    __shared__ __align__(16) uint32_t lds[kYWords + kZWords + 2 * kWaves + kPlanWords];  // rows: y | x^32, as the tile kernel's
     uint32_t* ldsY = lds;
-    uint32_t* ldsX = lds + kYWords;
-    uint32_t* ldsZ = ldsX + kXWords;
+    uint32_t* ldsZ = lds + kYWords;
     uint32_t* red = ldsZ + kZWords;
     CutRecord* prec = reinterpret_cast<CutRecord*>(red + 2 * kWaves);  // PLAN only
     uint32_t* plan_pbase = reinterpret_cast<uint32_t*>(prec + kPlanMax);
@@ -1740,20 +1762,20 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     // The table words this lane will put into LDS are asked for first (four
     // loads), so that they travel while the piece list / the items' descriptors
     // and headers are read.
-    static_assert(kXWords == 1024 && kZWords == 1024, "tables of 1024 words");
+    static_assert(kZWords == 1024, "table of 1024 words");
     constexpr int kRounds = (1024 + kThreads - 1) / kThreads;  // 1 at 1024 lanes
     constexpr int kYRounds = (kStagePairs + kThreads - 1) / kThreads;  // 2 at 1024 lanes
-    u32x4 ty[kYRounds];
-    uint32_t tx[kRounds], tz[kRounds];
+    u32x4 ty[kYRounds], tx[kYRounds];
+    uint32_t tz[kRounds];
 #pragma unroll
     for (int k = 0; k < kYRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
         ty[k] = stage_fetch(b.tabs->Yt, q < (uint32_t)kStagePairs ? q : 0u);
+        tx[k] = stage_fetch(b.tabs->Xt, q < (uint32_t)kStagePairs ? q : 0u);
     }
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads) < 1024u ? tid + (uint32_t)(k * kThreads) : 0u;
-        tx[k] = b.tabs->X[q];
         tz[k] = (&b.tabs->X2[0][0])[q];
     }
     uint32_t kb[32];
@@ -1781,15 +1803,15 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
 #pragma unroll
     for (int k = 0; k < kYRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
-        if (q < (uint32_t)kStagePairs) stage_store(ldsY, ty[k], q);
+        if (q < (uint32_t)kStagePairs) {
+            stage_store(ldsY, ty[k], q);
+            stage_store(ldsY, tx[k], q, 1u);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
         const uint32_t q = tid + (uint32_t)(k * kThreads);
-        if (q < 1024u) {
-            ldsX[q] = tx[k];
-            ldsZ[q] = tz[k];
-        }
+        if (q < 1024u) ldsZ[q] = tz[k];
     }
 #pragma unroll
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
@@ -1950,7 +1972,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
         // Lane residue -> place in the tile -> XOR over the workgroup.
         uint32_t r = 0;
 #pragma unroll
-        for (int cw = 0; cw < 4; ++cw) r = mul_x32(r ^ acc[cw], ldsX);
+        for (int cw = 0; cw < 4; ++cw) r = ki_mul8<kTabX>(r ^ acc[cw], L);
         {
             uint32_t prod = 0;
 #pragma unroll
