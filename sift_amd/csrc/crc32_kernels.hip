@@ -1603,7 +1603,8 @@ namespace {
 
 // One lane.  `r` is the register over the whole span: what the batch kernel does
 // after a wave_crc, per mode.
-__device__ __forceinline__ void verdict_record(const BatchArgs& b, const CutRecord* rp, uint32_t r) {
+__device__ __forceinline__ void verdict_record(const BatchArgs& b, const CutRecord* rp, uint32_t r,
+                                               bool have_stored = false, uint32_t stored = 0) {
     const uint8_t* end = b.base + rp->span_off + rp->span_len;
     const uint32_t item = rp->item;
     if (!b.verify) {
@@ -1617,7 +1618,7 @@ __device__ __forceinline__ void verdict_record(const BatchArgs& b, const CutReco
         for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
         status = 0;
     } else {
-        status = crc == be32(end) ? rp->cont : 5u;  // container.rs:60-63, then what follows
+        status = crc == (have_stored ? stored : be32(end)) ? rp->cont : 5u;  // container.rs:60-63, then what follows
     }
     b.out[item] = status;
     if (b.data_len) b.data_len[item] = status == 0 ? rp->dlen : 0u;
@@ -1631,6 +1632,21 @@ __device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecor
     for (uint32_t i = 0; i < tail_len; ++i) r = crc_step_byte(r, end[(int)i - (int)tail_len]);
     verdict_record(b, rp, r);
 }
+// The same with the 16-byte block the tail bytes lie in and the stored CRC already in
+// registers (the self-planned form asks for them with the header: fetched here they
+// were up to 19 dependent byte loads behind the record's last atomic).
+__device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecord* rp, uint32_t r, u32x4 tailv,
+                                              uint32_t stored) {
+    const uint8_t* end = b.base + rp->span_off + rp->span_len;
+    const uint32_t tail_len = (uint32_t)(reinterpret_cast<uint64_t>(end) & 15u);
+    for (uint32_t i = 0; i < tail_len; ++i) {
+        r = crc_step_byte(r, tailv[0] & 0xffu);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tailv[c] = (tailv[c] >> 8) | (tailv[c + 1] << 24);
+        tailv[3] >>= 8;
+    }
+    verdict_record(b, rp, r, true, stored);
+}
 
 // Few items (n <= kPlanMax, not the document mode): no filing pass.  Every
 // workgroup of the piece kernel works the plan out for itself, identically: lane
@@ -1640,15 +1656,17 @@ __device__ __forceinline__ void finish_record(const BatchArgs& b, const CutRecor
 // span to stream (an error before the CRC, or a span under 32 bytes, walked by
 // the lane) get their verdict from workgroup 0 alone.  Returns the piece total.
 __device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, const uint64_t* inl, CutRecord* prec,
-                                               uint32_t* pbase_lds, uint32_t* total_lds) {
+                                               uint32_t* pbase_lds, uint32_t* total_lds, uint64_t d_off,
+                                               uint64_t d_avail, u32x4& pre_tail, uint32_t& pre_stored) {
     const uint32_t tid = threadIdx.x;
+    pre_tail = u32x4{0u, 0u, 0u, 0u};
+    pre_stored = 0u;
     if (tid < 64u) {
         const uint32_t i = tid;
         uint32_t np = 0, level = 0, dlen = 0;
         uint64_t span_off = 0, span_len = 0;
         if (i < b.n) {
-            const uint64_t off = inl ? inl[2u * i] : b.offsets[i];
-            const uint64_t avail = inl ? inl[2u * i + 1u] : b.lens[i];
+            const uint64_t off = d_off, avail = d_avail;  // asked for at the top of the kernel
             const uint8_t* ptr = b.base + off;
             uint32_t status = 0;
             bool pending = true;
@@ -1697,6 +1715,11 @@ __device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, const uint64_
             }
             if (pending) {
                 const uint64_t A = reinterpret_cast<uint64_t>(b.base) + span_off;
+                // what the record's finisher will need, asked for now (lane i of wave 0 keeps
+                // item i's): the block its trailing bytes lie in and the stored CRC behind it
+                const uint64_t E = A + span_len;
+                pre_tail = *reinterpret_cast<const u32x4*>((E & 15u) ? (E & ~15ull) : (A & ~15ull));
+                if (b.verify == 1) pre_stored = be32(reinterpret_cast<const uint8_t*>(E));
                 const uint64_t body = ((A + span_len) & ~15ull) - (A & ~15ull);
                 level = span_level(body, b.cut.piece_min_log2);
                 const uint32_t plog = b.cut.piece_min_log2 + level;
@@ -1759,9 +1782,31 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
 
     const CutArgs& c = b.cut;
     const uint32_t tid = threadIdx.x;
-    // The table words this lane will put into LDS are asked for first (four
-    // loads), so that they travel while the piece list / the items' descriptors
-    // and headers are read.
+#if defined(SIFT_TRACE_PIECES)  // timing-only build (tools/trace_pieces.hip): 100 MHz clock at six points per workgroup, into out[]
+#define SIFT_PTRACE(slot) \
+    if (tid == 0) b.out[64 + (slot) * 256 + blockIdx.x] = (uint32_t)wall_clock64()
+#else
+#define SIFT_PTRACE(slot)
+#endif
+    SIFT_PTRACE(0);
+    // What the plan hangs on is asked for first: the items' descriptors (lane i of wave 0:
+    // item i), or the length of the filed piece list.  Then the table words this lane will
+    // put into LDS.  Tables are staged and the lane's matrix rows computed while those
+    // first answers -- and, in the self-planned form, the chunk headers behind them -- are
+    // on their way (round 2 staged after the plan: two trips to memory with idle lanes,
+    // then 0.8 us of vector work with an idle memory system).
+    uint64_t d_off = 0, d_avail = 0;
+    unsigned long long reserved = 0;
+    if (PLAN) {
+        const uint64_t* inl = nullptr;
+        if constexpr (INL) inl = d.v;
+        if (tid < 64u && tid < b.n) {
+            d_off = inl ? inl[2u * tid] : b.offsets[tid];
+            d_avail = inl ? inl[2u * tid + 1u] : b.lens[tid];
+        }
+    } else {
+        reserved = *c.pieces;
+    }
     static_assert(kZWords == 1024, "table of 1024 words");
     constexpr int kRounds = (1024 + kThreads - 1) / kThreads;  // 1 at 1024 lanes
     constexpr int kYRounds = (kStagePairs + kThreads - 1) / kThreads;  // 2 at 1024 lanes
@@ -1780,21 +1825,18 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     }
     uint32_t kb[32];
     kb[0] = b.tabs->Kt[tid];
-    uint32_t total;
-    if (PLAN) {
-        const uint64_t* inl = nullptr;
-        if constexpr (INL) inl = d.v;
-        total = plan_items(b, inl, prec, plan_pbase, plan_pbase + kPlanMax);
-    } else {
-        const unsigned long long reserved = *c.pieces;
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t total = 0, g = 1;
+    if (!PLAN) {
+        // the filed list: most batches file nothing, and a workgroup without a window leaves
+        // before it stages anything
         total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
-    }
-    // window: about two per workgroup once the list is long enough, at most 64 pieces
-    uint32_t g = total / (gridDim.x * 2u);
-    g = g < 1u ? 1u : (g > 64u ? 64u : g);
-    if ((uint64_t)blockIdx.x * g >= total) {
-        if (!PLAN && tid == 0) leave_pieces(c, gridDim.x);
-        return;
+        g = total / (gridDim.x * 2u);
+        g = g < 1u ? 1u : (g > 64u ? 64u : g);
+        if ((uint64_t)blockIdx.x * g >= total) {
+            if (tid == 0) leave_pieces(c, gridDim.x);
+            return;
+        }
     }
 
     const KiLane L = ki_lane(tid);
@@ -1817,7 +1859,23 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 pre_tail = {0u, 0u, 0u, 0u};  // PLAN, wave 0, lane i: item i's tail block and stored CRC
+    uint32_t pre_stored = 0;
+    if (PLAN) {
+        const uint64_t* inl = nullptr;
+        if constexpr (INL) inl = d.v;
+        // (ends with the workgroup's barrier, which also covers the tables staged above)
+        total = plan_items(b, inl, prec, plan_pbase, plan_pbase + kPlanMax, d_off, d_avail, pre_tail, pre_stored);
+        // window: about two per workgroup once the list is long enough, at most 64 pieces
+        g = total / (gridDim.x * 2u);
+        g = g < 1u ? 1u : (g > 64u ? 64u : g);
+        if ((uint64_t)blockIdx.x * g >= total) return;
+    } else {
+        __syncthreads();
+    }
+    SIFT_PTRACE(1);
 
     // Wave 0 hands residues to their records through a three-stage pipeline, so
     // that it never waits for an atomic it has just issued (the other 15 waves
@@ -1845,7 +1903,15 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
                 if (PLAN) /* no filing pass re-initialises the record: leave it zero */               \
                     __hip_atomic_exchange(&c.recs[s2_slot].arrived, 0ull, __ATOMIC_RELAXED,           \
                                           __HIP_MEMORY_SCOPE_AGENT);                                  \
-                finish_record(b, r2_, (uint32_t)v_);                                                  \
+                if (PLAN) {                                                                           \
+                    u32x4 t_;                                                                         \
+                    for (int q_ = 0; q_ < 4; ++q_)                                                    \
+                        t_[q_] = (uint32_t)__builtin_amdgcn_readlane((int)pre_tail[q_], (int)s2_slot); \
+                    finish_record(b, r2_, (uint32_t)v_, t_,                                           \
+                                  (uint32_t)__builtin_amdgcn_readlane((int)pre_stored, (int)s2_slot)); \
+                } else {                                                                              \
+                    finish_record(b, r2_, (uint32_t)v_);                                              \
+                }                                                                                     \
             }                                                                                         \
         }                                                                                             \
         s2_slot = s1_slot;                                                                            \
@@ -1969,6 +2035,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
             --ntiles;
         }
 
+        SIFT_PTRACE(2);
         // Lane residue -> place in the tile -> XOR over the workgroup.
         uint32_t r = 0;
 #pragma unroll
@@ -2003,12 +2070,59 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
         }
         p += run;
     }
+    SIFT_PTRACE(3);
+    if (PLAN && b.n == 1u) {
+        // ONE item: every workgroup holds its whole share of the item's register in cur_x, and
+        // the workgroups that took part are 0 .. P - 1.  They meet as the tile kernel's groups
+        // do: shards of 32 on a 64-bit word each (arrival bits | XOR of the residues), one
+        // returning atomic per level, the last arriver of the last level finishes the item.
+        // (Through the record's accumulator and arrival count -- XOR, then add, then two
+        // swaps, each waited for, all 256 workgroups on the same two words -- a single
+        // 16 MiB chunk spent 6.5 of its 15 us here.)  The words are the first 8 bytes of
+        // every other record slot of the stream's block: zero between calls, put back to
+        // zero by each level's last arriver.
+        if (tid == 0) {
+            unsigned long long* words = reinterpret_cast<unsigned long long*>(c.recs);  // 128 bytes apart
+            const uint32_t P = (total + g - 1u) / g < gridDim.x ? (total + g - 1u) / g : gridDim.x;
+            const uint32_t nshards = (P + 31u) >> 5;
+            const uint32_t shard = blockIdx.x >> 5, bit = blockIdx.x & 31u;
+            const uint32_t members = P - (shard << 5) < 32u ? P - (shard << 5) : 32u;
+            const uint32_t full1 = members == 32u ? 0xFFFFFFFFu : (1u << members) - 1u;
+            const uint32_t x = cur_slot == kVoidSlot ? 0u : cur_x;
+            unsigned long long* w1 = words + 16u * (1u + shard);
+            unsigned long long old = __hip_atomic_fetch_xor(w1, ((unsigned long long)(1u << bit) << 32) | x,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((uint32_t)(old >> 32) | (1u << bit)) == full1) {
+                const uint32_t xs = (uint32_t)old ^ x;
+                __hip_atomic_fetch_xor(w1, ((unsigned long long)full1 << 32) | xs, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t sum = xs;
+                bool last = true;
+                if (nshards > 1u) {
+                    const uint32_t full2 = nshards == 32u ? 0xFFFFFFFFu : (1u << nshards) - 1u;
+                    old = __hip_atomic_fetch_xor(words, ((unsigned long long)(1u << shard) << 32) | xs,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = ((uint32_t)(old >> 32) | (1u << shard)) == full2;
+                    if (last) {
+                        sum = (uint32_t)old ^ xs;
+                        __hip_atomic_fetch_xor(words, ((unsigned long long)full2 << 32) | sum, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (last) finish_record(b, prec, sum, pre_tail, pre_stored);  // lane 0 holds item 0's
+            }
+        }
+        SIFT_PTRACE(5);
+        return;
+    }
     if (tid < 64u) {  // drain the pipeline: three stages
         SIFT_COMMIT_ADVANCE();
         cur_slot = kVoidSlot;
         SIFT_COMMIT_ADVANCE();
+        SIFT_PTRACE(4);
         SIFT_COMMIT_ADVANCE();
     }
+    SIFT_PTRACE(5);
 #undef SIFT_COMMIT_ADVANCE
     if (!PLAN && tid == 0) leave_pieces(c, gridDim.x);
 }
