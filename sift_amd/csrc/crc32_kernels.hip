@@ -1164,6 +1164,27 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
 }
 
+// N little-endian words from ANY byte address p (p .. p + 4N - 1 must be readable): N + 1
+// aligned dword loads and N funnel shifts.  The chunk headers and stored CRCs of the
+// container format sit at arbitrary addresses; read a byte at a time (be32) a document's
+// 37 header and verdict bytes were 37 load instructions whose 64 lanes each touch a
+// different cache line -- four times as many requests to the CU's one memory pipe as the
+// document's payload makes.  The dword behind the last byte wanted may lie outside the
+// buffer, so it is only asked for when the window really reaches into it.
+template <int N>
+__device__ __forceinline__ void load_words(const uint8_t* p, uint32_t (&out)[N]) {
+    typedef __attribute__((address_space(1))) const uint32_t* GlobalWord;
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t o = (uint32_t)a & 3u;
+    const GlobalWord q = (GlobalWord)(a & ~3ull);
+    uint32_t v[N + 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = q[j];
+    v[N] = q[o ? N : N - 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) out[j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], o);
+}
+
 // x <- x * c, c given as the 32 rows c * x^k of its matrix: lane k of each
 // half-wave holds row k and contributes it when bit 31-k of x is set; a 5-step
 // butterfly sums the rows.  Every lane of the wave returns the product.
@@ -1457,7 +1478,79 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         uint64_t len0 = 0;                  // MODE 0: the buffer's length
         bool span0 = false, span1 = false;  // CRC spans still to do
         const uint8_t* ptr = b.base;
-        if (have) {
+        // Wide reads (load_words) of what the verdict will compare, made here, beside the
+        // headers: the stored CRC(s), and in the document mode the AMRG chunk's type.  Only
+        // when every item of the turn is long enough for the windows to lie inside it
+        // (wave-uniform; any valid item is); otherwise the byte-wise code below and in C.
+        bool pre = false;                   // stored0 (and type0) are in registers
+        bool pre2 = false;                  // MODE 2: so are the SEND chunk's header and, if it is empty, its CRC
+        uint32_t stored0 = 0, type0 = 0, stored2 = 0;
+        uint64_t avail_w = 0;
+        if (MODE != 0 && have) {
+            avail_w = b.lens[i];
+            ptr = b.base + b.offsets[i];
+        }
+        // lanes without an item read where lane 0's item is (the wave's first lane always has one)
+        const uint8_t* ptr0 = reinterpret_cast<const uint8_t*>(uniform64(reinterpret_cast<uint64_t>(ptr)));
+        if (MODE == 1 && __all(!have || avail_w >= 12u)) {  // Chunk::read, container.rs:47-66
+            pre = true;
+            uint32_t w[1];
+            load_words<1>(have ? ptr : ptr0, w);
+            const uint32_t n = __builtin_bswap32(w[0]);
+            if (have) {
+                if (n > b.chunk_limit) status = 3;  // :49-52
+                else {
+                    dlen = n;
+                    if (avail_w < 12ull + (uint64_t)n) status = 1;  // read_exact fails, :54-60
+                }
+            }
+            span0 = have && status == 0;
+            load_words<1>(span0 ? ptr + 8ull + dlen : ptr0, w);
+            stored0 = __builtin_bswap32(w[0]);
+        } else if (MODE == 2 && __all(!have || avail_w >= 32u)) {  // read_document's framing, document.rs:62-77
+            pre = true;
+            uint32_t h[5];
+            load_words<5>(have ? ptr : ptr0, h);  // magic (9 bytes) | length | type
+            if (have) {
+                if (h[0] != 0x46495389u || h[1] != 0x1A0A0D54u || (h[2] & 0xffu) != 0x0Au) status = 1;  // container.rs:113
+                if (status == 0) {  // read_chunk_head on the AMRG chunk
+                    const uint32_t n = __builtin_bswap32(__builtin_amdgcn_alignbyte(h[3], h[2], 1));
+                    if (n > b.chunk_limit) status = 3;
+                    else {
+                        dlen = n;
+                        if (avail_w - 9u < 12ull + (uint64_t)n) status = 1;
+                    }
+                }
+                type0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(h[4], h[3], 1));
+            }
+            span0 = have && status == 0;
+            const uint64_t pos2 = 21ull + dlen;  // the SEND chunk starts right behind
+            if (__all(!span0 || avail_w >= pos2 + 12u)) {
+                // one window: the AMRG chunk's stored CRC | the SEND chunk's length | type | its CRC if it is empty
+                pre2 = true;
+                uint32_t w[4];
+                load_words<4>(span0 ? ptr + pos2 - 4u : ptr0, w);
+                stored0 = __builtin_bswap32(w[0]);
+                type2 = __builtin_bswap32(w[2]);
+                stored2 = __builtin_bswap32(w[3]);
+                if (span0) {  // read_chunk_head on the SEND chunk
+                    const uint32_t n2 = __builtin_bswap32(w[1]);
+                    if (n2 > b.chunk_limit) st2 = 3;
+                    else {
+                        d2 = n2;
+                        if (avail_w - pos2 < 12ull + (uint64_t)n2) st2 = 1;
+                    }
+                    span1 = st2 == 0;
+                }
+            } else if (span0) {
+                uint32_t w[1];
+                load_words<1>(ptr + pos2 - 4u, w);  // inside the item: avail >= 21 + dlen
+                stored0 = __builtin_bswap32(w[0]);
+                if (avail_w - pos2 >= 8u) type2 = be32(ptr + pos2 + 4);
+                st2 = read_chunk_head(ptr + pos2, avail_w - pos2, b.chunk_limit, &d2);
+                span1 = st2 == 0;
+            }
+        } else if (have) {
             const uint64_t off = b.offsets[i], avail = b.lens[i];
             ptr = b.base + off;
             if (MODE == 0) {  // crc.rs:28-34 on buffer i
@@ -1557,22 +1650,22 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 #pragma unroll
                 for (uint32_t k = 0; k < 4u; ++k) slot[k] = (uint8_t)(crc >> (24u - 8u * k));
             } else if (MODE == 1) {
-                if (crc != be32(chunk + 8ull + dlen)) status = 5;  // container.rs:60-63
+                if (crc != (pre ? stored0 : be32(chunk + 8ull + dlen))) status = 5;  // container.rs:60-63
             } else {
                 // everything the checks below look at is requested at once: read where
                 // each check stands, behind the branch of the one before, they were up
                 // to four trips to memory one after the other
-                const uint32_t stored0 = be32(chunk + 8ull + dlen), type0 = be32(chunk + 4);
-                uint32_t stored2 = 0, type2c = 0;
+                const uint32_t s0 = pre ? stored0 : be32(chunk + 8ull + dlen), t0 = pre ? type0 : be32(chunk + 4);
+                uint32_t s2 = 0, t2 = 0;
                 if (st2 == 0) {
-                    stored2 = be32(send + 8ull + d2);
-                    type2c = be32(send + 4);
+                    s2 = pre2 && d2 == 0u ? stored2 : be32(send + 8ull + d2);
+                    t2 = pre2 ? type2 : be32(send + 4);
                 }
-                if (crc != stored0) status = 5;                             // container.rs:60-63
-                else if (type0 != 0x414D5247u) status = 1;                  // expect_type(AMRG)
+                if (crc != s0) status = 5;                                  // container.rs:60-63
+                else if (t0 != 0x414D5247u) status = 1;                     // expect_type(AMRG)
                 else if (st2) status = st2;                                 // read_chunk on the SEND chunk, before its crc
-                else if ((r1 ^ 0xFFFFFFFFu) != stored2) status = 5;
-                else if (type2c != 0x53454E44u) status = 1;                 // expect_type(SEND)
+                else if ((r1 ^ 0xFFFFFFFFu) != s2) status = 5;
+                else if (t2 != 0x53454E44u) status = 1;                     // expect_type(SEND)
             }
         }
         b.out[i] = status;
