@@ -60,13 +60,13 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // l + 16 share).  And with rows of 256 bytes the whole address is ONE v_perm_b32: byte 1 =
 // the operand's byte k_j, byte 0 = the lane's offset in the row, byte 2 = the 64 KiB block:
 //     block 0  [0, 64 K)      rows of 256 B:  G = x^(8*256) C = 8 | X = x^32 C = 8
-//     block 1  [64 K, 128 K)  rows of 256 B:  K2 = x^(128*4) C = 8 | K1 = x^(128*2) C = 4 |
-//                                             K0 = x^128 C = 2 | K3 = x^(128*8) C = 2
+//     block 1  [64 K, 128 K)  rows of 256 B:  K2 = x^(128*4) C = 8 | K1 = x^(128*2), K0 = x^128,
+//                                             K3 = x^(128*8), C = 2 each (32 bytes of a row free)
 //     block 2  [128 K, 160 K) rows of 128 B:  Y1 = x^(8*1024) C = 8 (the wave path; the address is
 //                                             the permute of doubled offsets shifted right by one)
-// (K2 is the 4-lane shapes' chain step, 48 lookups a pass at 256 bytes, K1 the 2-lane
-// shape's; K0 and K3 are used 4 and at most 16 times a pass.  With Y1 at C = 4 to make room
-// for them, 16 KiB items were 9 % slower.)
+// (K2 is the 4 x 4 shape's chain step, 48 lookups a pass at 256 bytes; K0, K1 and K3 are used
+// 4 times a pass each since the two-chain shapes fold before they join.  With Y1 at C = 4
+// 16 KiB items were 9 % slower.)
 // The reference's own CRC_TABLE (crc.rs:2-20) is X's k = 3 slice: (b << 24) * x^32 = b * x^8.
 // The image is built on the host (DeviceTables::batch_image) and copied in 16 bytes a lane.
 // The tables start at LDS address 0 (the kernel's one __shared__ array; checked in its
@@ -140,8 +140,7 @@ template <int J>
 __device__ __forceinline__ uint32_t ki_mulK_add(uint32_t a, uint32_t w, const KiLane& L) {
     static_assert(J >= 0 && J <= 3, "K0..K3");
     if constexpr (J == 2) return ki_mul_add<0>(a, w, L, L.p8 | 0x10000u, L.q8 | 0x10000u);
-    else if constexpr (J == 1) return ki_mul_add<128>(a, w, L, (L.p8 & 0x3f3fu) | 0x10000u, (L.q8 & 0x3f3fu) | 0x10000u);
-    else return ki_mul_add<(J == 0 ? 192 : 224)>(a, w, L, (L.p8 & 0x1f1fu) | 0x10000u, (L.q8 & 0x1f1fu) | 0x10000u);
+    else return ki_mul_add<(J == 1 ? 128 : J == 0 ? 160 : 192)>(a, w, L, (L.p8 & 0x1f1fu) | 0x10000u, (L.q8 & 0x1f1fu) | 0x10000u);
 }
 // One byte of the reference's recurrence WITH its table (crc.rs:31), the table being X's
 // k = 3 slice; t8 = the lane's offset of such an entry in a row (ki_t8).
@@ -964,6 +963,8 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
     // in (one address per group), issued behind the first data vectors
     u32x4 tw = {0u, 0u, 0u, 0u};
     u32x4 acc = {0u, 0u, 0u, 0u};
+    uint32_t folded = 0;     // two-chain shapes: the lane's register, already folded and joined
+    bool is_folded = false;  // wave-uniform
     {
         // A round is one tile per chain; rounds are counted from the first (t = 0, the
         // only one that can be short of tiles).  In round t chain c holds tile
@@ -1063,15 +1064,34 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
         }
         // the lane's chains: chain c is GW vectors (x^(128*GW), lane-join table LG) ahead
         // of chain c - 1.  Steps no group of the wave needs are skipped (all zero so far).
-        acc = ch[NCH - 1];
+        // With two chains each is folded over its four words FIRST (x^32 table, 8 copies)
+        // and the two 32-bit registers joined with 4 lookups: joining the 128-bit
+        // accumulators took 16 in a table that only has room for 2 or 4 copies (LDS bank
+        // conflicts 41 % of the LDS cycles at 512-byte items).
+        if constexpr (NCH == 2) {
+            if (__any(ntile > 1)) {
+                uint32_t f1 = 0, f0 = 0;
 #pragma unroll
-        for (int c = NCH - 2; c >= 0; --c) {
-            if (__any(ntile > c + 1)) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = ki_mulK_add<LG>(acc[k], ch[c][k], L);
+                for (int k = 0; k < 4; ++k) {
+                    f1 = ki_mul8<kTabX>(f1 ^ ch[1][k], L);
+                    f0 = ki_mul8<kTabX>(f0 ^ ch[0][k], L);
+                }
+                folded = ki_mulK_add<LG>(f1, f0, L);
+                is_folded = true;
             } else {
+                acc = ch[0];  // chain 1 is empty in every group of the wave
+            }
+        } else {
+            acc = ch[NCH - 1];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
+            for (int c = NCH - 2; c >= 0; --c) {
+                if (__any(ntile > c + 1)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = ki_mulK_add<LG>(acc[k], ch[c][k], L);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] ^= ch[c][k];
+                }
             }
         }
     }
@@ -1082,9 +1102,12 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
     // lane's place, x^(128 * (GW - 1 - lane)), costs 7 instructions a bit; this path is
     // VALU-bound -- a wave64 instruction takes four cycles -- so lookups win.  Four
     // register multiplies instead of the x^32 table were tried too: 1.9x slower.)
-    uint32_t r = 0;
+    uint32_t r = folded;
+    if (!is_folded) {  // wave-uniform
+        r = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r = ki_mul8<kTabX>(r ^ acc[c], L);
+        for (int c = 0; c < 4; ++c) r = ki_mul8<kTabX>(r ^ acc[c], L);
+    }
     r = ki_mulK_add<0>(r, __shfl_xor(r, 1, 64), L);
     if constexpr (LG > 1) r = ki_mulK_add<1>(r, __shfl_xor(r, 2, 64), L);
     if constexpr (LG > 2) r = ki_mulK_add<2>(r, __shfl_xor(r, 4, 64), L);
@@ -1302,6 +1325,9 @@ constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16
 #ifndef SIFT_END_FRAMED_MAX
 #define SIFT_END_FRAMED_MAX 1024
 #endif
+#ifndef SIFT_DOC_PAIR
+#define SIFT_DOC_PAIR 0  // 1: the document mode pairs its passes of up to 128 bytes too (it then spills 48 bytes a lane)
+#endif
 constexpr uint32_t kGroup4Max = SIFT_GROUP4_MAX;  // widest span of a turn that runs on 4-lane groups
 static_assert(kGroup4Max >= 128 && kGroup4Max <= 256, "4-lane groups take one round of 2 or 4 chains");
 constexpr uint32_t kEndFramedMax = SIFT_END_FRAMED_MAX;  // ... that is framed from the spans' ends
@@ -1372,8 +1398,8 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
             // make them spill; the document mode: none, it has no registers for that)
             const uint32_t top2 = class_at(first + 2u * per_pass - 1u);  // >= top: the spans are in class order
             const bool same2 = lgw == 1u ? top2 == kClass64 : lgw == 2u ? top2 <= kClass256 : top2 <= kClassEndFramed;
-            const bool pair = MODE != 2 && first + per_pass < cnt && same2 &&
-                              (top2 <= kClass128 || (MODE == 0 && top2 <= kClassEndFramed));
+            const bool pair = first + per_pass < cnt && same2 &&
+                              ((top2 <= kClass128 && (MODE != 2 || SIFT_DOC_PAIR)) || (MODE == 0 && top2 <= kClassEndFramed));
             if (pair) {
                 const uint32_t ia = first + (lane >> lgw), ib = ia + per_pass;
                 const bool ona = ia < cnt, onb = ib < cnt;
