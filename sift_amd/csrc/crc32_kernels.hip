@@ -1621,6 +1621,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
         // ---- B: the CRCs ----  (one instance of the span code: the document mode
         // runs it twice, SEND span first)
         uint32_t r0 = 0, r1 = 0;
+        uint32_t after0 = 0;  // MODE 2: the file's status if its AMRG chunk's CRC matches
         bool filed = false;
         bool send_done = false;
         if (MODE == 2 && !__any(span1 && d2 != 0u)) {
@@ -1640,17 +1641,22 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             const uint8_t* sp = MODE == 0 ? ptr : (slot ? send + 4 : ptr + kChunkAt + 4);
             const uint64_t sl = MODE == 0 ? len0 : 4ull + (slot ? d2 : dlen);
             const bool may_file = slot == 0 && b.cut.counts != nullptr;
-            if (MODE == 2 && may_file && __any(span0 && sl > (uint64_t)b.cut.wave_max)) {
-                // A long AMRG chunk goes to the piece kernel with everything the reference
-                // does AFTER that chunk's CRC check (document.rs:65-74) already decided.
+            if (MODE == 2 && slot == 0) {
+                // Everything the reference does AFTER the AMRG chunk's CRC check (document.rs:
+                // 65-74) is decided HERE, before that chunk's passes: the SEND chunk's register
+                // is known, and one word (`after0`) crosses the passes instead of the SEND
+                // chunk's checks, length, type, stored CRC and register.  A long AMRG chunk
+                // takes the same word to the piece kernel.
                 if (span0) {
-                    cont = be32(ptr + 13) != 0x414D5247u ? 1u : 0u;  // expect_type(AMRG)
-                    if (cont == 0)
-                        cont = st2 ? st2
-                                   : ((r1 ^ 0xFFFFFFFFu) != be32(send + 8 + d2) ? 5u
-                                      : be32(send + 4) != 0x53454E44u        ? 1u
-                                                                              : 0u);
+                    const uint32_t t0 = pre ? type0 : be32(ptr + 13);
+                    cont = t0 != 0x414D5247u ? 1u : st2;  // expect_type(AMRG), then read_chunk on the SEND chunk
+                    if (cont == 0) {
+                        const uint32_t s2 = pre2 && d2 == 0u ? stored2 : be32(send + 8ull + d2);
+                        const uint32_t t2 = pre2 ? type2 : be32(send + 4);
+                        cont = (r1 ^ 0xFFFFFFFFu) != s2 ? 5u : t2 != 0x53454E44u ? 1u : 0u;  // its crc, expect_type(SEND)
+                    }
                 }
+                after0 = cont;
             }
             crc_spans<MODE>(b, slot ? span1 : span0, reinterpret_cast<uint64_t>(sp), sl, i, cont, dlen, may_file,
                             r, f, L, lane);
@@ -1678,20 +1684,8 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
             } else if (MODE == 1) {
                 if (crc != (pre ? stored0 : be32(chunk + 8ull + dlen))) status = 5;  // container.rs:60-63
             } else {
-                // everything the checks below look at is requested at once: read where
-                // each check stands, behind the branch of the one before, they were up
-                // to four trips to memory one after the other
-                const uint32_t s0 = pre ? stored0 : be32(chunk + 8ull + dlen), t0 = pre ? type0 : be32(chunk + 4);
-                uint32_t s2 = 0, t2 = 0;
-                if (st2 == 0) {
-                    s2 = pre2 && d2 == 0u ? stored2 : be32(send + 8ull + d2);
-                    t2 = pre2 ? type2 : be32(send + 4);
-                }
-                if (crc != s0) status = 5;                                  // container.rs:60-63
-                else if (t0 != 0x414D5247u) status = 1;                     // expect_type(AMRG)
-                else if (st2) status = st2;                                 // read_chunk on the SEND chunk, before its crc
-                else if ((r1 ^ 0xFFFFFFFFu) != s2) status = 5;
-                else if (t2 != 0x53454E44u) status = 1;                     // expect_type(SEND)
+                const uint32_t s0 = pre ? stored0 : be32(chunk + 8ull + dlen);
+                status = crc != s0 ? 5u : after0;  // container.rs:60-63, then what was decided before the passes
             }
         }
         b.out[i] = status;
