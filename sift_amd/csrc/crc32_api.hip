@@ -1271,6 +1271,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     b.base = static_cast<const uint8_t*>(d_base);
     b.n = n;
     b.state = state;
+    b.state_m32 = gf2_mulmod(verify ? 0xFFFFFFFFu : state, gf2_xpow(x2n(), 0xFFFFFFFFull - 32ull));
     b.xor_out = xor_out;
     b.verify = (uint32_t)verify;
     b.chunk_limit = SIFT_CHUNK_SIZE_LIMIT;

@@ -188,6 +188,7 @@ struct BatchArgs {
     const uint64_t* lens;
     uint32_t n;
     uint32_t state;       // starting register for every buffer (crc mode)
+    uint32_t state_m32;   // (the mode's starting register) * x^-32: 0xFFFFFFFF in the chunk modes, `state` in crc mode
     uint32_t xor_out;     // crc mode: XORed into each result
     uint32_t verify;      // 0: out[i] = compute(state, buffer i) ^ xor_out
                           // 1: out[i] = status of Chunk::read on item i (SIFT_OK / SIFT_ERR_*)

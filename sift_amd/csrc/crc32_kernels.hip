@@ -892,6 +892,7 @@ template <int NCH>
 struct GroupLoads {
     u32x4 ch[NCH];
     u32x4 tw;
+    u32x4 h0;  // vector 0 of the group's span, in every lane of the group
 };
 template <int GW, int NCH, bool ENDF>
 __device__ __forceinline__ void group_request(const uint8_t* ptr, uint32_t len, bool on, uint32_t lane,
@@ -921,10 +922,11 @@ __device__ __forceinline__ void group_request(const uint8_t* ptr, uint32_t len, 
         g.ch[c] = *vec(on && tile0 + c < ntile && vi >= 0 ? vi : 0);
     }
     if constexpr (!ENDF) g.tw = *vec(tail_len ? nvec : 0);
+    if constexpr (ONE_ROUND) g.h0 = *vec(0);
 }
 
 template <int GW, int NCH, bool ENDF>
-__device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+__device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t len, uint64_t state2, bool on,
                                                    const KiLane& L, uint32_t lane,
                                                    const GroupLoads<NCH>* pre = nullptr) {
     static_assert((GW == 8 && NCH == 2) || (GW == 4 && (NCH == 4 || NCH == 2)) || (GW == 2 && NCH == 2), "group shape");
@@ -980,46 +982,107 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
         const int32_t nround = ONE_ROUND ? (ntile > 0 ? 1 : 0) : (ntile + NCH - 1) >> LCH;
         const int32_t tile0 = NCH * (nround - 1);
         const int32_t vi0 = nvec - GW * (tile0 + 1) + (int32_t)lg;  // round 0, chain c: vector vi0 - GW * c
-        // Vector 0 needs moving up (or its head masking) and vectors 0 and 1 the state bytes
-        // (at bytes lead .. lead + 3 of the two).  A lane holds at most one of them: in round 0, chain vi0 >> LG (its
-        // vector there is vi0 mod GW), or -- when vector 0 is alone in its tile -- vector 1
-        // in round 1, last chain.
-        const bool head0 = on && vi0 >= 0 && (vi0 & (GW - 1)) <= 1;
-        const bool head1 = !ONE_ROUND && on && vi0 == 1 - GW;
-        const int32_t hvi = head1 ? 1 : (vi0 & (GW - 1)), hc = vi0 >> LG;
-        const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, lead, state);
         u32x4 ch[NCH];
-        {
-            bool ex[NCH];
+        bool head1 = false;  // 8-lane shape: this lane holds vector 1 in round 1 (state bytes reach into it)
+        if constexpr (ONE_ROUND || ENDF) {
+            // Vector 0 needs moving up (or its head masking) and the starting register.  The
+            // register goes into vector 0 alone: as the word state * x^-32 in the four zero bytes
+            // just BEFORE the first message byte when there are four (lead >= 4; a word there
+            // weighs x^(8 len + 32)), else as the state itself over the first four message bytes
+            // (bytes lead .. lead + 3 < 8).  (Round 2 always used the second form, which reaches
+            // into vector 1 for lead > 12: a second fix-up, in another chain or another round.)
+            // Every lane fetches vector 0 of its group's span itself (h0: one address a group)
+            // and works the fix-up out; the lane that holds vector 0 -- in round 0, chain
+            // vi0 >> LG, if vi0 is a multiple of GW -- takes the result.  (Round 2 picked the
+            // vector out of the lane's chains and put it back: 8 selects a chain.)
+            const bool own0 = on && vi0 >= 0 && (vi0 & (GW - 1)) == 0;
+            const int32_t hc = vi0 >> LG;
+            {
+                bool ex[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int32_t vi = vi0 - GW * c;
-                ex[c] = on && tile0 + c < ntile && vi >= 0;
-                ch[c] = pre ? pre->ch[c] : *vec(ex[c] ? vi : 0);
-            }
-            if constexpr (!ENDF) tw = pre ? pre->tw : *vec(tail_len ? nvec : 0);
-            __builtin_amdgcn_sched_barrier(0);
-            u32x4 hw = {0u, 0u, 0u, 0u};  // the lane's vector 0 or 1, if it has one
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const bool hd = head0 && hc == c;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ch[c][k] = ex[c] ? ch[c][k] : 0u;
-                    hw[k] = hd ? ch[c][k] : hw[k];
+                for (int c = 0; c < NCH; ++c) {
+                    const int32_t vi = vi0 - GW * c;
+                    ex[c] = on && tile0 + c < ntile && vi >= 0;
+                    ch[c] = pre ? pre->ch[c] : *vec(ex[c] ? vi : 0);
                 }
+                if constexpr (!ENDF) tw = pre ? pre->tw : *vec(tail_len ? nvec : 0);
+                // (the 8-lane shape picks vector 0 out of its two chains instead: there the
+                // extra load costs more than the 8 selects)
+                u32x4 h0 = {0u, 0u, 0u, 0u};
+                if constexpr (ONE_ROUND) h0 = pre ? pre->h0 : *vec(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!ONE_ROUND) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const bool hd = own0 && hc == c;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) h0[k] = hd ? ch[c][k] : h0[k];
+                    }
+                }
+                const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+                u32x4 up = ENDF ? shl_bytes(h0, lead) : h0 & mask_head(ones, lead);
+                {
+                    const uint32_t sw = lead >= 4u ? (uint32_t)(state2 >> 32) : (uint32_t)state2;
+                    const uint32_t pb = lead >= 4u ? lead - 4u : lead;  // 0 .. 11: the word lies inside vector 0
+                    const uint32_t bs = 8u * (pb & 3u), wi = pb >> 2;
+                    const uint32_t lo = sw << bs, hi = bs ? sw >> (32u - bs) : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) up[k] ^= (wi == k ? lo : 0u) ^ (wi + 1u == k ? hi : 0u);
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const bool hd = own0 && hc == c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ch[c][k] = hd ? up[k] : ex[c] ? ch[c][k] : 0u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
-            const u32x4 up = ENDF ? shl_bytes(hw, lead) : hw & mask_head(ones, lead);
+        } else {
+            // The 8-lane shape on memory's own 16-byte blocks (spans over 1 KiB) keeps round 2's
+            // fix-up (the state over the first four message bytes, which may reach into vector 1;
+            // the vector picked out of the lane's chains): with the form above mixed
+            // 32..4080-byte items were 6 % slower (framed from the end, 1000-byte items are 8 %
+            // faster with it).
+            // Vector 0 needs moving up (or its head masking) and vectors 0 and 1 the state bytes
+            // (at bytes lead .. lead + 3 of the two).  A lane holds at most one of them: in round 0, chain vi0 >> LG (its
+            // vector there is vi0 mod GW), or -- when vector 0 is alone in its tile -- vector 1
+            // in round 1, last chain.
+            const bool head0 = on && vi0 >= 0 && (vi0 & (GW - 1)) <= 1;
+            head1 = on && vi0 == 1 - GW;
+            const int32_t hvi = head1 ? 1 : (vi0 & (GW - 1)), hc = vi0 >> LG;
+            const u32x4 delta = fold_state_word(u32x4{0u, 0u, 0u, 0u}, hvi, lead, (uint32_t)state2);
+            {
+                bool ex[NCH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hw[k] = (hvi == 0 ? up[k] : hw[k]) ^ delta[k];
+                for (int c = 0; c < NCH; ++c) {
+                    const int32_t vi = vi0 - GW * c;
+                    ex[c] = on && tile0 + c < ntile && vi >= 0;
+                    ch[c] = pre ? pre->ch[c] : *vec(ex[c] ? vi : 0);
+                }
+                if constexpr (!ENDF) tw = pre ? pre->tw : *vec(tail_len ? nvec : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 hw = {0u, 0u, 0u, 0u};  // the lane's vector 0 or 1, if it has one
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const bool hd = head0 && hc == c;
+                for (int c = 0; c < NCH; ++c) {
+                    const bool hd = head0 && hc == c;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ch[c][k] = hd ? hw[k] : ch[c][k];
+                    for (int k = 0; k < 4; ++k) {
+                        ch[c][k] = ex[c] ? ch[c][k] : 0u;
+                        hw[k] = hd ? ch[c][k] : hw[k];
+                    }
+                }
+                const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+                const u32x4 up = ENDF ? shl_bytes(hw, lead) : hw & mask_head(ones, lead);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hw[k] = (hvi == 0 ? up[k] : hw[k]) ^ delta[k];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const bool hd = head0 && hc == c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ch[c][k] = hd ? hw[k] : ch[c][k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         // Rounds 1 .. : round t + 1's vectors are requested before round t is stepped (a
         // round read and then stepped is a trip to memory per 256 bytes of span with
@@ -1043,7 +1106,7 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t == 1 && __any(head1)) {  // worked out again here: four registers fewer across the loop
-                    const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, lead, state);
+                    const u32x4 d1 = fold_state_word(u32x4{0u, 0u, 0u, 0u}, 1, lead, (uint32_t)state2);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) w[NCH - 1][k] ^= head1 ? d1[k] : 0u;
                 }
@@ -1126,9 +1189,9 @@ __device__ __forceinline__ uint32_t group_crc_body(const uint8_t* ptr, uint32_t 
 }
 
 template <int GW, int NCH, bool ENDF>
-__device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint32_t state, bool on,
+__device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint32_t len, uint64_t state2, bool on,
                                               KiLane L, uint32_t lane) {
-    return group_crc_body<GW, NCH, ENDF>(ptr, len, state, on, L, lane);
+    return group_crc_body<GW, NCH, ENDF>(ptr, len, state2, on, L, lane);
 }
 
 // Two passes in one: both spans' vectors are requested before the first is worked on, so a
@@ -1136,22 +1199,22 @@ __device__ __attribute__((noinline)) uint32_t group_crc(const uint8_t* ptr, uint
 // the low (a) and high (b) word.
 template <int GW, int NCH, bool ENDF>
 __device__ __forceinline__ uint64_t group_crc_pair_body(const uint8_t* pa, uint32_t la, bool ona, const uint8_t* pb,
-                                                        uint32_t lb, bool onb, uint32_t state, const KiLane& L,
+                                                        uint32_t lb, bool onb, uint64_t state2, const KiLane& L,
                                                         uint32_t lane) {
     GroupLoads<NCH> ga, gb;
     group_request<GW, NCH, ENDF>(pa, la, ona, lane, ga);
     group_request<GW, NCH, ENDF>(pb, lb, onb, lane, gb);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t ra = group_crc_body<GW, NCH, ENDF>(pa, la, state, ona, L, lane, &ga);
+    const uint32_t ra = group_crc_body<GW, NCH, ENDF>(pa, la, state2, ona, L, lane, &ga);
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t rb = group_crc_body<GW, NCH, ENDF>(pb, lb, state, onb, L, lane, &gb);
+    const uint32_t rb = group_crc_body<GW, NCH, ENDF>(pb, lb, state2, onb, L, lane, &gb);
     return ((uint64_t)rb << 32) | ra;
 }
 template <int GW, int NCH, bool ENDF>
 __device__ __attribute__((noinline)) uint64_t group_crc_pair(const uint8_t* pa, uint32_t la, bool ona,
-                                                             const uint8_t* pb, uint32_t lb, bool onb, uint32_t state,
+                                                             const uint8_t* pb, uint32_t lb, bool onb, uint64_t state2,
                                                              KiLane L, uint32_t lane) {
-    return group_crc_pair_body<GW, NCH, ENDF>(pa, la, ona, pb, lb, onb, state, L, lane);
+    return group_crc_pair_body<GW, NCH, ENDF>(pa, la, ona, pb, lb, onb, state2, L, lane);
 }
 
 // CRC of a span under 32 bytes by ONE LANE (64 spans per wave at a time): the
@@ -1346,6 +1409,7 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
                                           uint32_t& res, bool& filed, const KiLane& L,
                                           uint32_t lane) {
     const uint32_t state = MODE == 0 ? b.state : 0xFFFFFFFFu;
+    const uint64_t state2 = ((uint64_t)b.state_m32 << 32) | state;  // with state * x^-32 (group_crc_body's head)
     // under 32 bytes: a lane each
     const bool tiny = want && sl <= (uint64_t)kTinyMax;
     if (__any(tiny)) {
@@ -1409,10 +1473,10 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
                 const uint32_t la = __shfl(len32, ma, 64), lb = __shfl(len32, mb, 64);
                 // (the smallest shape is inlined: 3 % off a turn of 64-byte chunks; the next one
                 // inlined as well makes the document mode spill)
-                const uint64_t rr = lgw == 1u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                    : lgw == 3u ? group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                    : top2 <= kClass128 ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state, L, lane)
-                                                        : group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state, L, lane);
+                const uint64_t rr = lgw == 1u ? group_crc_pair_body<2, 2, true>(pa, la, ona, pb, lb, onb, state2, L, lane)
+                                    : lgw == 3u ? group_crc_pair<8, 2, true>(pa, la, ona, pb, lb, onb, state2, L, lane)
+                                    : top2 <= kClass128 ? group_crc_pair<4, 2, true>(pa, la, ona, pb, lb, onb, state2, L, lane)
+                                                        : group_crc_pair<4, 4, true>(pa, la, ona, pb, lb, onb, state2, L, lane);
                 const uint32_t k = rank - first;  // which of the 2 * per_pass spans, for the lanes it concerns
                 const int src = (int)((k & (per_pass - 1u)) << lgw);
                 const uint32_t va = __shfl((uint32_t)rr, src, 64), vb = __shfl((uint32_t)(rr >> 32), src, 64);
@@ -1425,11 +1489,11 @@ __device__ __forceinline__ void crc_spans(const BatchArgs& b, bool want, uint64_
                 const uint8_t* p = reinterpret_cast<const uint8_t*>(shfl64(sp, mine));
                 const uint32_t l = __shfl(len32, mine, 64);
                 uint32_t r;
-                if (lgw == 1u) r = group_crc<2, 2, true>(p, l, state, on, L, lane);
-                else if (lgw == 2u && top <= kClass128) r = group_crc<4, 2, true>(p, l, state, on, L, lane);
-                else if (lgw == 2u) r = group_crc<4, 4, true>(p, l, state, on, L, lane);
-                else if (top <= kClassEndFramed) r = group_crc<8, 2, true>(p, l, state, on, L, lane);
-                else r = group_crc<8, 2, false>(p, l, state, on, L, lane);
+                if (lgw == 1u) r = group_crc<2, 2, true>(p, l, state2, on, L, lane);
+                else if (lgw == 2u && top <= kClass128) r = group_crc<4, 2, true>(p, l, state2, on, L, lane);
+                else if (lgw == 2u) r = group_crc<4, 4, true>(p, l, state2, on, L, lane);
+                else if (top <= kClassEndFramed) r = group_crc<8, 2, true>(p, l, state2, on, L, lane);
+                else r = group_crc<8, 2, false>(p, l, state2, on, L, lane);
                 // back to the lanes that hold the spans: rank - first is the group that did it
                 const uint32_t v = __shfl(r, (int)(((rank - first) & (per_pass - 1u)) << lgw), 64);
                 if (mid && rank >= first && rank < first + per_pass) res = v;
@@ -1943,6 +2007,10 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     if (!PLAN) {
         // the filed list: most batches file nothing, and a workgroup without a window leaves
         // before it stages anything
+        // nothing reserved: no record was filed either (a record has at least one piece), the
+        // call's counters are all zero as they stand, and there is nothing to count out of
+        // (256 workgroups counting themselves out on one word was half of this launch's 4 us)
+        if (reserved == 0ull) return;
         total = reserved < c.cap_pieces ? (uint32_t)reserved : c.cap_pieces;
         g = total / (gridDim.x * 2u);
         g = g < 1u ? 1u : (g > 64u ? 64u : g);
