@@ -349,9 +349,9 @@ void build_tables(DeviceTables* t) {
             for (uint32_t c = 0; c < 8; ++c) t->batch_image[32768 + b * 32 + 4 * c + k] = t->Y1[k * 256 + b];  // block 2: Y1
             for (uint32_t c = 0; c < 2; ++c) {
                 t->batch_image[16384 + b * 64 + 32 + 4 * c + k] = t->K[1][k * 256 + b];  // K1
-                t->batch_image[16384 + b * 64 + 40 + 4 * c + k] = t->K[0][k * 256 + b];  // K0
-                t->batch_image[16384 + b * 64 + 48 + 4 * c + k] = t->K[3][k * 256 + b];  // K3
+                t->batch_image[16384 + b * 64 + 56 + 4 * c + k] = t->K[3][k * 256 + b];  // K3
             }
+            for (uint32_t c = 0; c < 4; ++c) t->batch_image[16384 + b * 64 + 40 + 4 * c + k] = t->K[0][k * 256 + b];  // K0
         }
     const uint32_t x128 = gf2_xpow(x2n(), 128);
     uint32_t p = kOne;

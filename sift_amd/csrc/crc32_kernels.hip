@@ -60,8 +60,8 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 // l + 16 share).  And with rows of 256 bytes the whole address is ONE v_perm_b32: byte 1 =
 // the operand's byte k_j, byte 0 = the lane's offset in the row, byte 2 = the 64 KiB block:
 //     block 0  [0, 64 K)      rows of 256 B:  G = x^(8*256) C = 8 | X = x^32 C = 8
-//     block 1  [64 K, 128 K)  rows of 256 B:  K2 = x^(128*4) C = 8 | K1 = x^(128*2), K0 = x^128,
-//                                             K3 = x^(128*8), C = 2 each (32 bytes of a row free)
+//     block 1  [64 K, 128 K)  rows of 256 B:  K2 = x^(128*4) C = 8 | K1 = x^(128*2) C = 2 | K0 = x^128 C = 4 |
+//                                             K3 = x^(128*8) C = 2
 //     block 2  [128 K, 160 K) rows of 128 B:  Y1 = x^(8*1024) C = 8 (the wave path; the address is
 //                                             the permute of doubled offsets shifted right by one)
 // (K2 is the 4 x 4 shape's chain step, 48 lookups a pass at 256 bytes; K0, K1 and K3 are used
@@ -140,7 +140,8 @@ template <int J>
 __device__ __forceinline__ uint32_t ki_mulK_add(uint32_t a, uint32_t w, const KiLane& L) {
     static_assert(J >= 0 && J <= 3, "K0..K3");
     if constexpr (J == 2) return ki_mul_add<0>(a, w, L, L.p8 | 0x10000u, L.q8 | 0x10000u);
-    else return ki_mul_add<(J == 1 ? 128 : J == 0 ? 160 : 192)>(a, w, L, (L.p8 & 0x1f1fu) | 0x10000u, (L.q8 & 0x1f1fu) | 0x10000u);
+    else if constexpr (J == 0) return ki_mul_add<160>(a, w, L, (L.p8 & 0x3f3fu) | 0x10000u, (L.q8 & 0x3f3fu) | 0x10000u);
+    else return ki_mul_add<(J == 1 ? 128 : 224)>(a, w, L, (L.p8 & 0x1f1fu) | 0x10000u, (L.q8 & 0x1f1fu) | 0x10000u);
 }
 // One byte of the reference's recurrence WITH its table (crc.rs:31), the table being X's
 // k = 3 slice; t8 = the lane's offset of such an entry in a row (ki_t8).

@@ -4,7 +4,7 @@
 # then python tools/summarize_batch_pmc.py r02
 set -e
 R=$PWD
-RND=${1:-r02}
+RND=${1:-r03}
 export TMPDIR=/tmp
 cd /tmp
 for size in 64 100 256 512 1024 3000 16384; do

@@ -3,7 +3,7 @@
 device-resident, pageable and pinned input, next to Python's zlib.crc32 on one
 core.  Results are checked against zlib.crc32.  The reference's own CPU loop
 is timed by bench.py (`cpu_baseline`, ~0.62 GB/s, size-independent); the
-crossover in DESIGN.md uses that figure.  Writes gpurun_out/size_sweep.json."""
+crossover in DESIGN.md uses that figure.  One JSON document on stdout (progress on stderr)."""
 import json
 import os
 import statistics as st
@@ -78,8 +78,7 @@ for n in SIZES:
                  "gpu_host_input_GBps": round(n / host_us / 1e3, 3),
                  "gpu_pinned_input_us": round(pin_us, 2), "gpu_pinned_input_GBps": round(n / pin_us / 1e3, 3),
                  "zlib_us": round(z_us, 2)})
-    print(rows[-1], flush=True)
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "size_sweep.json"), "w") as f:
-    json.dump({"note": "device-resident unless 'host_input' / 'pinned_input'; zlib = Python zlib.crc32, 1 core; the "
-                       "reference's own loop runs ~0.62 GB/s (bench.py cpu_baseline)", "rows": rows}, f, indent=1)
+    print(rows[-1], file=sys.stderr, flush=True)
+json.dump({"note": "device-resident unless 'host_input' / 'pinned_input'; zlib = Python zlib.crc32, 1 core; the "
+                   "reference's own loop runs ~0.62 GB/s (bench.py cpu_baseline)", "rows": rows}, sys.stdout, indent=1)
+print()

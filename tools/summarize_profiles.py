@@ -91,11 +91,21 @@ steps20 = None
 hits20 = glob.glob(os.path.join(GO, f"{rnd}_trace20/*/*kernel_trace.csv"))
 if hits20:
     rows20 = []
+    first_other = None  # the secondary rows start with the first batch / piece kernel launch
     with open(hits20[0]) as f:
-        for r in csv.DictReader(f):
-            if KERNEL in r["Kernel_Name"] and "true" in r["Kernel_Name"]:
-                rows20.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        allrows = list(csv.DictReader(f))
+    for r in allrows:
+        if ("crc32_batch_kernel" in r["Kernel_Name"] or "crc32_pieces_kernel" in r["Kernel_Name"]):
+            t = int(r["Start_Timestamp"])
+            first_other = t if first_other is None else min(first_other, t)
+    for r in allrows:
+        if KERNEL in r["Kernel_Name"] and "true" in r["Kernel_Name"]:
+            t0, d = int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            if d > 100.0 and (first_other is None or t0 < first_other):  # a whole-GiB launch of the main phase
+                rows20.append((t0, d))
     rows20.sort()
+    # the main phase's launches end with the 64 untimed launches of the 64 MiB / 1 MiB rows' set-up? no: those
+    # are shorter than 100 us; its last 20 whole-GiB launches are the timed steps
     last = sorted(d for _, d in rows20[-20:])
     if last:
         steps20 = {"launches_in_trace": len(rows20), "timed_launches": len(last), "avg_us": sum(last) / len(last),
@@ -134,6 +144,44 @@ print(json.dumps(summary["rocprof_kernel_trace"], indent=1))
 print(json.dumps(steps20, indent=1))
 print(json.dumps(summary["derived"], indent=1))
 print(json.dumps(traffic, indent=1))
+
+# Every kernel of the traced bench command (bench.py --steps 20 --warmup 5, secondary rows
+# included), as clusters of like durations per kernel: each secondary row of the bench line
+# times one kernel on one workload 20 times (plus its warm-up calls), so its kernel_us must
+# be the median of one cluster here.
+if hits20:
+    by = collections.defaultdict(list)
+    with open(hits20[0]) as f:
+        for r in csv.DictReader(f):
+            if "crc32_" in r["Kernel_Name"]:
+                name = r["Kernel_Name"].split("(")[0].replace("void sift::", "").replace("sift::", "")
+                by[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    clusters = {}
+    for name, ds in by.items():
+        ds.sort()
+        groups, cur = [], [ds[0]]
+        for d in ds[1:]:
+            if d > cur[0] * 1.25:  # a new cluster starts 25 % above the last one's smallest member
+                groups.append(cur)
+                cur = [d]
+            else:
+                cur.append(d)
+        groups.append(cur)
+        clusters[name] = [{"launches": len(g), "median_us": round(g[len(g) // 2], 2), "min_us": round(g[0], 2),
+                           "max_us": round(g[-1], 2)} for g in groups if len(g) >= 5]
+    with open(os.path.join(PR, f"{rnd}_bench_kernel_clusters.json"), "w") as f:
+        json.dump({"round": rnd, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 "
+                                            "--no-cpu-baseline", "kernels": clusters}, f, indent=1)
+    hs = glob.glob(os.path.join(GO, f"{rnd}_trace20/*/*kernel_stats.csv"))
+    if hs:
+        with open(max(hs, key=os.path.getmtime)) as f:
+            srows = [r for r in csv.DictReader(f) if "crc32_" in r["Name"]]
+        with open(os.path.join(PR, f"{rnd}_bench_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=srows[0].keys())
+            w.writeheader()
+            for r in srows:
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
 
 # the other files tools/collect_profiles.sh leaves under gpurun_out/
 import shutil
