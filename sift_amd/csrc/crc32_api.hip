@@ -169,8 +169,9 @@ class CopyCrew {
 struct StreamScratch {
     std::mutex m;                    // one call at a time issues its launch sequence on this stream's scratch
     std::atomic<uint32_t*> compute_ws{nullptr};  // kStreamBlockBytes, zero between calls (sift_crc32_compute_* with workspace NULL)
-    uint8_t* batch = nullptr;        // batch entry points: counters | records | piece list; counters zero between calls
+    uint8_t* batch = nullptr;        // batch entry points: head (kCutHeadBytes, zero between calls) | records | piece list
     size_t batch_bytes = 0;
+    unsigned wide_calls = 0;         // wide-plan calls issued on this block (which of its two flags is this call's)
     // Pageable host descriptors of up to kDescStageBytes per call are copied by the
     // CPU into one of two pinned buffers which the kernels read in place (no copy
     // command: hipMemcpyAsync from pageable memory costs 100-300 us of fixed time
@@ -1287,8 +1288,14 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // full is walked by its own wave instead (same bits, slower).
     bool cut = g_batch_cut.load() != 0;
     const int tuned_wave_max = g_batch_wave_max.load(), piece_log2 = g_batch_piece_log2.load();
+    // The longest span a wave keeps.  A wave alone streams 2.7 GB/s, so waves pay once there
+    // are enough of them: measured crossover with the piece kernel (tools/cut_grid.sh,
+    // profiles/r03_cut_grid.txt) at 64 KiB for 2048 items, 128-256 KiB for 3000-4000.
     const uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max
-                                                 : (n >= 4096u ? (256u << 10) : (32u << 10));
+                              : n > 3072u        ? (256u << 10)
+                              : n > 2048u        ? (128u << 10)
+                              : n > 1024u        ? (64u << 10)
+                                                 : (32u << 10);
     // Lengths the host can read (host or pinned arrays), not too many of them: if no
     // item can hold a span longer than wave_max, nothing will be filed and the call is
     // the wave kernel alone -- no scratch, no second launch (6 us of an otherwise 8 us call).
@@ -1323,6 +1330,9 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // Few items (and not the document mode, whose second chunk needs the wave
     // kernel): no filing pass, the piece kernel plans for itself.
     const bool plan = cut && n <= kPlanMax && verify != 2 && g_batch_plan.load() != 0;
+    // Up to kWideMax items (same exception): the batch kernel leaves the long spans alone and
+    // the piece kernel finds them itself -- no filing, no piece list.
+    const bool wide = cut && !plan && n <= kWideMax && verify != 2 && g_batch_plan.load() != 0;
     if (plan) {
         uint8_t* blk = nullptr;
         rc = stream_block_held(&ss, st, &blk);
@@ -1331,7 +1341,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         b.cut.wave_max = wave_max;
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     } else if (cut) {
-        const size_t need = kCutHeadBytes + sizeof(CutRecord) * cap_recs + 4 * cap_pieces;
+        const size_t need = wide ? kCutHeadBytes : kCutHeadBytes + sizeof(CutRecord) * cap_recs + 4 * cap_pieces;
         if (ss.batch_bytes < need) {
             // grow-only; the new block is published before the old one is freed (in
             // stream order, behind the calls that used it), so a failure in between
@@ -1339,7 +1349,9 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
             const size_t want = std::max<size_t>(need + need / 2, 512u << 10);
             uint8_t* fresh = nullptr;
             SIFT_HIP(hipMallocAsync(reinterpret_cast<void**>(&fresh), want, st));
-            launch_clear(reinterpret_cast<uint32_t*>(fresh), 64, st);  // the three counters
+            // the head is zero between calls: counters, flags, the wide plan's accumulators
+            launch_clear(reinterpret_cast<uint32_t*>(fresh), (int)(kCutHeadBytes / 4), st);
+            ss.wide_calls = 0;
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 (void)hipFreeAsync(fresh, st);
@@ -1351,13 +1363,22 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
             if (old) SIFT_HIP(hipFreeAsync(old, st));
         }
         uint8_t* blk = ss.batch;
-        b.cut.counts = reinterpret_cast<uint32_t*>(blk);
-        b.cut.left = reinterpret_cast<uint32_t*>(blk + 64);
-        b.cut.pieces = reinterpret_cast<unsigned long long*>(blk + 128);
-        b.cut.recs = reinterpret_cast<CutRecord*>(blk + kCutHeadBytes);
-        b.cut.piece_rec = reinterpret_cast<uint32_t*>(blk + kCutHeadBytes + sizeof(CutRecord) * cap_recs);
-        b.cut.cap_recs = (uint32_t)cap_recs;
-        b.cut.cap_pieces = (uint32_t)cap_pieces;
+        if (wide) {
+            // flags take turns: this call's, and the next wide call's (cleared by this call's batch kernel)
+            uint32_t* flags = reinterpret_cast<uint32_t*>(blk + kCutFlagsOffset);
+            b.cut.long_flag = flags + (ss.wide_calls & 1u);
+            b.cut.clear_flag = flags + ((ss.wide_calls + 1u) & 1u);
+            ++ss.wide_calls;
+            b.cut.recs = reinterpret_cast<CutRecord*>(blk + kCutWideOffset);  // pairs of words (crc32_pieces_kernel<2>)
+        } else {
+            b.cut.counts = reinterpret_cast<uint32_t*>(blk);
+            b.cut.left = reinterpret_cast<uint32_t*>(blk + 64);
+            b.cut.pieces = reinterpret_cast<unsigned long long*>(blk + 128);
+            b.cut.recs = reinterpret_cast<CutRecord*>(blk + kCutHeadBytes);
+            b.cut.piece_rec = reinterpret_cast<uint32_t*>(blk + kCutHeadBytes + sizeof(CutRecord) * cap_recs);
+            b.cut.cap_recs = (uint32_t)cap_recs;
+            b.cut.cap_pieces = (uint32_t)cap_pieces;
+        }
         b.cut.wave_max = wave_max;
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     }
@@ -1491,7 +1512,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     hipEvent_t e0 = nullptr, e1 = nullptr;  // measurement: pairs that ride on the dispatches
     if (plan) {
         prof_take(c, 2, &e0, &e1);
-        launch_pieces(b, c->groups_max, true, use_inline ? &inl : nullptr, st, e0, e1);
+        launch_pieces(b, c->groups_max, 1, use_inline ? &inl : nullptr, st, e0, e1);
         SIFT_HIP(hipGetLastError());
     } else {
         prof_take(c, 1, &e0, &e1);
@@ -1499,7 +1520,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         SIFT_HIP(hipGetLastError());
         if (cut) {
             prof_take(c, 2, &e0, &e1);
-            launch_pieces(b, c->groups_max, false, nullptr, st, e0, e1);
+            launch_pieces(b, c->groups_max, wide ? 2 : 0, nullptr, st, e0, e1);
             SIFT_HIP(hipGetLastError());
         }
     }

@@ -146,6 +146,9 @@ constexpr int kPieceMinLog2 = 16;            // 64 KiB: four 16 KiB tiles
 constexpr uint32_t kMaxPiecesPerItem = 1024; // level is raised until np fits (up to kMaxLevel)
 constexpr uint32_t kMaxLevel = 14;
 constexpr uint32_t kPlanMax = 64;             // up to this many items the piece kernel plans for itself (one lane each)
+constexpr uint32_t kWideMax = 4096;           // up to this many it plans the LONG ones (four items a lane, all lanes), the
+                                              // batch kernel keeps the others: no filing (one returning atomic pair per long
+                                              // item on two words: 23 ns an item, 25 us of a 190 us call on 1024 x 1 MiB)
 constexpr uint32_t kVoidSlot = 0xFFFFFFFFu;  // piece_rec entry of a reservation that did not fit           // pieces of at most 1 GiB (32-bit buffer offsets)
 
 struct CutRecord {
@@ -175,8 +178,16 @@ struct CutArgs {
     uint32_t cap_recs, cap_pieces;
     uint32_t wave_max;           // spans of up to this many bytes stay on the wave that found them
     uint32_t piece_min_log2;     // smallest piece, log2 bytes (kPieceMinLog2 unless tuned)
+    // Wide plan (64 < n <= kWideMax): a wave that meets a long span leaves it alone and raises
+    // *long_flag; the piece kernel returns at once when it is not raised.  Two flag words take
+    // turns from call to call: the batch kernel of a call clears the one the NEXT call will use.
+    // `recs` is then kWideMax pairs of 64-bit words (accumulator, pieces arrived), zero between calls.
+    uint32_t* long_flag;
+    uint32_t* clear_flag;
 };
-constexpr size_t kCutHeadBytes = 256;  // counts @0, left @64, pieces @128
+constexpr size_t kCutFlagsOffset = 192;                     // counts @0, left @64, pieces @128, the two flags @192
+constexpr size_t kCutWideOffset = 256;                      // wide plan's accumulators
+constexpr size_t kCutHeadBytes = 256 + 16 * kWideMax;       // head of the batch scratch block: zero between calls
 
 // Batch kernel (one wave per buffer).  Buffer i is `lens[i]` bytes at
 // `base + offsets[i]`.  In the verify / write modes the item is a serialized
@@ -211,7 +222,8 @@ struct InlineDesc {
 };
 
 void launch_batch(const BatchArgs& b, int groups, void* stream, void* ev_start = nullptr, void* ev_stop = nullptr);
-void launch_pieces(const BatchArgs& b, int groups, bool plan, const InlineDesc* inl, void* stream,
+// plan: 0 the filed list, 1 up to kPlanMax items planned by one lane each, 2 the wide plan
+void launch_pieces(const BatchArgs& b, int groups, int plan, const InlineDesc* inl, void* stream,
                    void* ev_start = nullptr, void* ev_stop = nullptr);
 void launch_clear(uint32_t* words, int n, void* stream);
 void launch_tiles(const TileArgs& t, const FinalArgs& f, const CombineMats& m, int groups,

@@ -295,3 +295,96 @@ def test_cut_full_size_chunks(gpu):
         assert container.write_chunk_crcs_device(buf, [5], [n + 12]).cpu().tolist() == [0]
         assert bytes(buf[5 + 8 + n:].cpu().numpy()) == struct.pack(">I", crc)
         del buf
+
+
+def _wide_lens(rng, count, long_share):
+    P = 65536
+    edge = [32768, 32769, 32784, 40000, P - 1, P, P + 1, P + 16, 2 * P - 1, 2 * P + 1, 3 * P + 7, 5 * P + 3,
+            (1 << 20) + 1, (3 << 20) + 12345, (9 << 20) + 5]
+    lens = []
+    for _ in range(count):
+        u = rng.random()
+        if u < long_share * 0.3:
+            lens.append(edge[int(rng.integers(0, len(edge)))])
+        elif u < long_share:
+            lens.append(int(rng.integers(32769, 600_000)))
+        else:
+            lens.append(int(rng.integers(0, 9000)))
+    return lens
+
+
+@pytest.mark.parametrize("count", [65, 300, 1500, 4096])
+def test_wide_plan_crc_mixed(gpu, tune, count):
+    # 65..4096 items: the batch kernel keeps the spans that fit a wave, the piece kernel plans
+    # the longer ones for itself (no filing).  Short and long items mixed, every alignment;
+    # against zlib and against the filed form; then a batch without long items (the piece
+    # kernel's flag stays down) and the first batch again (the two flags take turns).
+    from sift_amd import _lib as L
+    rng = np.random.default_rng(0x51F7 + 70 + count)
+    blob = rng.integers(0, 256, size=(48 << 20) + 4096, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    lens = _wide_lens(rng, count, 0.35 if count <= 300 else 0.08)
+    offs = [int(rng.integers(0, blob.size - n + 1)) for n in lens]
+    short = [min(n, 3000) for n in lens]
+    for state, xo in ((M, M), (0x1234ABCD, 0)):
+        want = [(zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo for o, n in zip(offs, lens)]
+        want_short = [(zlib.crc32(hb[o:o + n], state ^ M) ^ M) ^ xo for o, n in zip(offs, short)]
+        for off_arg, len_arg, short_arg in ((_dev(offs), _dev(lens), _dev(short)), (offs, lens, short)):
+            for rep in range(3):
+                got = gpu.compute_batch(state, d, off_arg, len_arg, xor_out=xo).cpu().numpy().view(np.uint32)
+                bad = [i for i, w in enumerate(want) if int(got[i]) != w]
+                assert not bad, (count, rep, bad[:5], [lens[i] for i in bad[:5]])
+                got = gpu.compute_batch(state, d, off_arg, short_arg, xor_out=xo).cpu().numpy().view(np.uint32)
+                assert [int(g) for g in got] == want_short, (count, rep, "no long item")
+        tune(L.TUNE_BATCH_PLAN, 0)
+        got = gpu.compute_batch(state, d, _dev(offs), _dev(lens), xor_out=xo).cpu().numpy().view(np.uint32)
+        assert [int(g) for g in got] == want, (count, "filed")
+        tune(L.TUNE_BATCH_PLAN, 1)
+    # other thresholds and piece sizes give the same bits (more items are long, pieces smaller or larger)
+    want = [zlib.crc32(hb[o:o + n]) for o, n in zip(offs, lens)]
+    for wave_max, plog in ((4096, 14), (100000, 18)):
+        tune(L.TUNE_BATCH_WAVE_MAX, wave_max)
+        tune(L.TUNE_BATCH_PIECE_LOG2, plog)
+        got = gpu.compute_batch(M, d, _dev(offs), _dev(lens), xor_out=M).cpu().numpy().view(np.uint32)
+        assert [int(g) for g in got] == want, (wave_max, plog)
+
+
+@pytest.mark.parametrize("count", [70, 900])
+def test_wide_plan_chunks_vs_oracle(gpu, oracle, tune, count):
+    # Chunk::read and Chunk::write's crc step on 70 / 900 serialized chunks, short and long,
+    # some damaged in each way the reference notices: wide plan against the oracle
+    from sift_amd import container, _lib as L
+    rng = np.random.default_rng(0x51F7 + 90 + count)
+    sizes = [int(x) for x in rng.integers(0, 5000, size=count)]
+    for k in rng.choice(count, size=max(14, count // 12), replace=False):
+        sizes[int(k)] = int(rng.choice([32764, 32765, 40000, 65532, 65536, 65540, 131072, 200001, (1 << 20) + 3,
+                                        (2 << 20) - 4, 3_000_000]))
+    stream, offs, avail, kinds = _chunks_case(oracle, rng, sizes)
+    extra = len(stream)
+    stream += struct.pack(">I", (1 << 30) + 1) + b"AMRG" + bytes(40)
+    offs.append(extra); avail.append(48); kinds.append("oversize")
+    offs.append(extra); avail.append(3); kinds.append("nolen")
+    d = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+    want = [oracle.read_chunk(stream[:o + a], o) for o, a in zip(offs, avail)]
+    want_status = [w[0] for w in want]
+    want_len = [w[3] if w[0] == 0 else 0 for w in want]
+    assert {0, 1, 3, 5} <= set(want_status)
+    for plan in (1, 0):
+        tune(L.TUNE_BATCH_PLAN, plan)
+        for off_arg, av_arg in ((offs, avail), (_dev(offs), _dev(avail))):
+            st, dl = container.read_chunks_device(d, off_arg, av_arg)
+            got = st.cpu().tolist()
+            bad = [(i, kinds[i], sizes[i] if i < len(sizes) else -1, got[i], want_status[i])
+                   for i in range(len(got)) if got[i] != want_status[i]]
+            assert not bad, (plan, bad[:6])
+            assert dl.cpu().tolist() == want_len
+    tune(L.TUNE_BATCH_PLAN, 1)
+    # Chunk::write: zero every crc slot of the intact chunks, have the device fill them, read back
+    ok = [i for i, k in enumerate(kinds) if k == "ok"]
+    d2 = d.clone()
+    for i in ok:
+        d2[offs[i] + 8 + sizes[i]:offs[i] + 12 + sizes[i]] = 0
+    st = container.write_chunk_crcs_device(d2, _dev([offs[i] for i in ok]), _dev([avail[i] for i in ok]))
+    assert set(st.cpu().tolist()) == {0}
+    assert bytes(d2.cpu().numpy()) == bytes(d.cpu().numpy())

@@ -62,6 +62,8 @@ int main(int argc, char** argv) {
     fill<<<1024, 256>>>(reinterpret_cast<uint32_t*>(blob), (total + 4096) / 4, 0x51F7);
     CK(hipDeviceSynchronize());
     SK(sift_init(0));
+    // SIFT_BENCH_WAVE_MAX=<bytes>: the longest span a wave keeps (above it the item is cut into pieces)
+    if (const char* e = getenv("SIFT_BENCH_WAVE_MAX")) SK(sift_tune(SIFT_TUNE_BATCH_WAVE_MAX, atoi(e)));
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -131,11 +133,15 @@ int main(int argc, char** argv) {
     printf("{\"rows\": [\n");
     bool first = true;
     // plain buffers back to back in the blob, descriptors in HBM and on the host
-    const size_t sizes[] = {64, 100, 128, 256, 512, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
+    // (batch_bench items <bytes> [count]: any size, and fewer buffers than fill the blob)
+    std::vector<size_t> sizes = {64, 100, 128, 256, 512, 1000, 1024, 3000, 16384, 65536, 262144, 1 << 20, 4 << 20, 16 << 20, 64 << 20, 256 << 20, 1 << 30};
+    if (only_items) sizes = {only_n};
+    const size_t only_count = only_items && argc >= 4 ? strtoull(argv[3], nullptr, 0) : 0;
     for (size_t size : sizes) {
-        if (only_items ? size != only_n : only_chunk) continue;
+        if (!only_items && only_chunk) continue;
         if (only_short && size > 65536) continue;
-        const uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
+        uint32_t n = (uint32_t)std::min<size_t>(total / size, 1 << 20);
+        if (only_count && only_count < n) n = (uint32_t)only_count;
         for (uint32_t i = 0; i < n; ++i) {
             off[i] = (uint64_t)i * size;
             len[i] = size;
