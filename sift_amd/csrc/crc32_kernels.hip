@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
+// a ^ (b & m) in one instruction (truth table 0x78): a step of a multiply by a constant
+// whose rows are in registers, m = one bit of the other factor spread over the word.
+__device__ __forceinline__ uint32_t xor_and(uint32_t a, uint32_t b, uint32_t m) {
+    return __builtin_amdgcn_bitop3_b32(a, b, m, 0x78);
+}
+
 // ---------------------------------------------------------------------------
 // Row-interleaved LDS tables of the batch kernel.
 //
@@ -225,7 +231,13 @@ __device__ __forceinline__ u32x4 load_vec(const u32x4* p) { return __builtin_non
 
 // One lane's vector of a whole tile: buffer_load_dwordx4, non-temporal (the
 // stream is read once; aux bit 1 = nt).
+#ifndef SIFT_ABL
+#define SIFT_ABL 0
+#endif
 __device__ __forceinline__ u32x4 load_tile(__amdgpu_buffer_rsrc_t srd, int voff, int soff) {
+#if SIFT_ABL == 2  // timing-only: no tile comes from memory
+    return u32x4{(uint32_t)voff, (uint32_t)soff, 1u, 2u};
+#endif
     return __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, /*aux*/ SIFT_LOAD_AUX);
 }
 
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     {
         uint32_t prod = 0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) prod ^= kb[i] & (0u - ((r >> (31 - i)) & 1u));
+        for (int i = 0; i < 32; ++i) prod = xor_and(prod, kb[i], (uint32_t)((int32_t)(r << i) >> 31));
         r = prod;
     }
 #endif
@@ -1390,9 +1402,6 @@ constexpr uint32_t kTinyMax = 31, kGroupMax = 4080;  // at most 255 vectors = 16
 #define SIFT_END_FRAMED_MAX 1024
 #endif
 #ifndef SIFT_DOC_PAIR
-#ifndef SIFT_ABL
-#define SIFT_ABL 0
-#endif
 #define SIFT_DOC_PAIR 0  // 1: the document mode pairs its passes of up to 128 bytes too (it then spills 48 bytes a lane)
 #endif
 constexpr uint32_t kGroup4Max = SIFT_GROUP4_MAX;  // widest span of a turn that runs on 4-lane groups
@@ -2252,101 +2261,148 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     } while (0)
 
     const uint32_t start_state = b.verify ? 0xFFFFFFFFu : b.state;
-    uint32_t parity = 0;
+    // The runs are taken two at a time: run k+1 is located and its first tiles are asked for
+    // BEFORE run k is reduced (fold, place, XOR over the workgroup, barrier, verdict: 1.3-1.6 us
+    // with nothing in flight -- as much as a run of 64 KiB takes to stream -- followed by a
+    // trip to memory before the next run's first fold).
+    struct Run {
+        uint32_t slot, np, plog, run, jl;
+        bool whole;
+        int64_t ntiles;  // tiles behind the first one and the first batch
+        const u32x4* pt;
+        int soff;
+        bool batch;      // the first batch (cur) was asked for
+        bool early;      // ... and the last tiles behind it too (odd): a short run is asked for whole
+        u32x4 acc, cur[kUnroll], odd[kUnroll > 1 ? kUnroll - 1 : 1];
+        u32x4 tail;      // PLAN 2, whole, wave 0: the block the trailing bytes lie in, the stored CRC
+        uint32_t stored;
+    };
+    constexpr int U = kUnroll;
+    const int voff = (int)(tid * 16u);
     uint64_t w = blockIdx.x;  // window index: this workgroup takes w, w + grid, ...
     uint32_t p = (uint32_t)w * g, wend = p + g < total ? p + g : total;
-    for (;; parity ^= 1u) {
-        if (p >= wend) {
-            w += gridDim.x;
-            if (w * g >= total) break;
-            p = (uint32_t)(w * g);
-            wend = p + g < total ? p + g : total;
+    // the next piece to take and its record's slot; false when the workgroup's windows are done
+    auto locate = [&](uint32_t& slot) __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (p >= wend) {
+                w += gridDim.x;
+                if (w * g >= total) return false;
+                p = (uint32_t)(w * g);
+                wend = p + g < total ? p + g : total;
+            }
+            if (PLAN == 1) {
+                // the last item whose piece base is <= p (items without pieces share the next one's base)
+                const uint32_t pb = plan_pbase[tid & 63u];
+                slot = 63u - (uint32_t)__builtin_clzll(__ballot(pb <= p));
+            } else if (PLAN == 2) {
+                // the first item whose pieces end behind p: which block of 64 items, then which of them
+                // (items past n and items without pieces end where their predecessor does)
+                const uint32_t blk = (uint32_t)__builtin_ctzll(__ballot(wide_end[(tid & 63u) * 64u + 63u] > p));
+                slot = blk * 64u + (uint32_t)__builtin_ctzll(__ballot(wide_end[blk * 64u + (tid & 63u)] > p));
+            } else {
+                slot = c.piece_rec[p];
+            }
+            if (slot != kVoidSlot) return true;
+            ++p;  // reservation that did not fit: its span was walked in place
         }
-        uint32_t slot;
-        if (PLAN == 1) {
-            // the last item whose piece base is <= p (items without pieces share the next one's base)
-            const uint32_t pb = plan_pbase[tid & 63u];
-            slot = 63u - (uint32_t)__builtin_clzll(__ballot(pb <= p));
-        } else if (PLAN == 2) {
-            // the first item whose pieces end behind p: which block of 64 items, then which of them
-            // (items past n and items without pieces end where their predecessor does)
-            const uint32_t blk = (uint32_t)__builtin_ctzll(__ballot(wide_end[(tid & 63u) * 64u + 63u] > p));
-            slot = blk * 64u + (uint32_t)__builtin_ctzll(__ballot(wide_end[blk * 64u + (tid & 63u)] > p));
-        } else {
-            slot = c.piece_rec[p];
-        }
-        if (slot == kVoidSlot) {  // reservation that did not fit: its span was walked in place
-            ++p;
-            continue;
-        }
+    };
+    // the run at p: its extent, and its first tile and first batch asked for
+    auto begin = [&](uint32_t slot) __attribute__((always_inline)) -> Run {
+        Run R;
+        R.slot = slot;
         uint64_t span_off, span_len;
-        uint32_t np, piece_base, plog;
+        uint32_t piece_base;
         if (PLAN == 2) {
             span_off = wide_span[2u * slot];
             span_len = wide_span[2u * slot + 1u];
             piece_base = slot ? wide_end[slot - 1u] : 0u;
-            np = wide_end[slot] - piece_base;
+            R.np = wide_end[slot] - piece_base;
             const uint64_t A0 = reinterpret_cast<uint64_t>(b.base) + span_off;
-            plog = c.piece_min_log2 + span_level(((A0 + span_len) & ~15ull) - (A0 & ~15ull), c.piece_min_log2);
+            R.plog = c.piece_min_log2 + span_level(((A0 + span_len) & ~15ull) - (A0 & ~15ull), c.piece_min_log2);
         } else {
             const CutRecord* rp = PLAN == 1 ? prec + slot : c.recs + slot;
             span_off = rp->span_off;
             span_len = rp->span_len;
-            np = rp->np;
+            R.np = rp->np;
             piece_base = rp->piece_base;
-            plog = c.piece_min_log2 + rp->level;
+            R.plog = c.piece_min_log2 + rp->level;
         }
         const uint32_t j = p - piece_base;
         // the run: pieces j .. j+run-1 of this record, inside the window, under 1 GiB
-        uint32_t run = wend - p;
-        if (run > np - j) run = np - j;
-        if (run > (1u << (30u - plog))) run = 1u << (30u - plog);
-        const uint32_t jl = j + run - 1u;  // last piece of the run: the run is weighted as jl is
+        R.run = wend - p;
+        if (R.run > R.np - j) R.run = R.np - j;
+        if (R.run > (1u << (30u - R.plog))) R.run = 1u << (30u - R.plog);
+        R.jl = j + R.run - 1u;  // last piece of the run: the run is weighted as jl is
         const uint64_t A = reinterpret_cast<uint64_t>(b.base) + span_off;
         const uint64_t Eb = (A + span_len) & ~15ull;
-        const uint64_t end_j = Eb - ((uint64_t)(np - 1u - jl) << plog);
-        const uint64_t start_j = j == 0 ? (A & ~15ull) : end_j - ((uint64_t)run << plog);
+        const uint64_t end_j = Eb - ((uint64_t)(R.np - 1u - R.jl) << R.plog);
+        const uint64_t start_j = j == 0 ? (A & ~15ull) : end_j - ((uint64_t)R.run << R.plog);
         const int64_t nvec = (int64_t)((end_j - start_j) >> 4);
         int64_t ntiles = (nvec + kTileVecs - 1) / kTileVecs;
         const u32x4* vbase = reinterpret_cast<const u32x4*>(start_j);
         // PLAN 2: the run is the whole span -- no other workgroup has a part of it, so its
         // register needs no accumulator; wave 0 asks now for what the verdict will need
         // (the block the trailing bytes lie in, the stored CRC) and gives it after the run.
-        const bool whole = PLAN == 2 && run == np;
-        if (whole && tid < 64u) {
+        R.whole = PLAN == 2 && R.run == R.np;
+        R.tail = u32x4{0u, 0u, 0u, 0u};
+        R.stored = 0u;
+        if (R.whole && tid < 64u) {
             const uint64_t E = A + span_len;
-            pre_tail = *reinterpret_cast<const u32x4*>((E & 15u) ? (E & ~15ull) : (A & ~15ull));
-            if (b.verify == 1) pre_stored = be32(reinterpret_cast<const uint8_t*>(E));
+            R.tail = *reinterpret_cast<const u32x4*>((E & 15u) ? (E & ~15ull) : (A & ~15ull));
+            if (b.verify == 1) R.stored = be32(reinterpret_cast<const uint8_t*>(E));
         }
-
         // First tile: the only one that can be partial (tiles are aligned to the
         // END of the piece); in piece 0 vector 0 carries the head mask and the
         // starting register.
-        u32x4 acc = {0u, 0u, 0u, 0u};
+        R.acc = u32x4{0u, 0u, 0u, 0u};
         const int64_t v0 = nvec - ntiles * (int64_t)kTileVecs;
         const int64_t vi = v0 + (int64_t)tid;
         if (vi >= 0) {
-            acc = load_vec(vbase + vi);
+            R.acc = load_vec(vbase + vi);
             if (j == 0 && vi == 0) {
                 const uint32_t h = (uint32_t)(A & 15u);
-                if (h) acc = mask_head(acc, h);
-                acc[0] ^= h ? gf2_mulmod(start_state, b.tabs->XinvH[h]) : start_state;
+                if (h) R.acc = mask_head(R.acc, h);
+                R.acc[0] ^= h ? gf2_mulmod(start_state, b.tabs->XinvH[h]) : start_state;
             }
         }
         --ntiles;
-        const u32x4* pt = vbase + v0 + kTileVecs;
-        const uint32_t run_bytes = (uint32_t)ntiles * (uint32_t)kTileBytes;
+        R.pt = vbase + v0 + kTileVecs;
+        R.soff = 0;
+        R.batch = ntiles >= U;
+        R.early = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) R.cur[u] = u32x4{0u, 0u, 0u, 0u};
+        if (R.batch) {
+            const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<u32x4*>(R.pt), /*stride*/ 0, (int)((uint32_t)ntiles * (uint32_t)kTileBytes), 0x00020000);
+#pragma unroll
+            for (int u = 0; u < U; ++u) R.cur[u] = load_tile(srd, voff, u * kTileBytes);
+            R.soff = U * kTileBytes;
+            ntiles -= U;
+            // a run that ends here (up to 2U tiles, 64 KiB) is asked for whole: its last tiles
+            // asked for when the run is streamed came a whole trip behind the reduction in between
+            R.early = ntiles < U;
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                R.odd[u] = u32x4{0u, 0u, 0u, 0u};
+                if (R.early && ntiles > u) R.odd[u] = load_tile(srd, voff, R.soff + u * kTileBytes);
+            }
+        }
+        R.ntiles = ntiles;
+        return R;
+    };
+    // the rest of the run's tiles: its register over the run's vectors, per lane
+    auto stream = [&](Run& R) __attribute__((always_inline)) {
+        u32x4 acc = R.acc;
+        int64_t ntiles = R.ntiles;
+        int soff = R.soff;
         const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<u32x4*>(pt), /*stride*/ 0, (int)run_bytes, 0x00020000);
-        const int voff = (int)(tid * 16u);
-        int soff = 0;
-        constexpr int U = kUnroll;
-        if (ntiles >= U) {
+            const_cast<u32x4*>(R.pt), /*stride*/ 0, (int)((uint32_t)soff + (uint32_t)ntiles * (uint32_t)kTileBytes),
+            0x00020000);
+        if (R.batch) {
             u32x4 cur[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = load_tile(srd, voff, soff + u * kTileBytes);
-            soff += U * kTileBytes;
-            ntiles -= U;
+            for (int u = 0; u < U; ++u) cur[u] = R.cur[u];
             // as in the tile kernel: two register sets in turn, one batch in flight
             u32x4 nxt[U];
             while (ntiles >= 2 * U) {
@@ -2380,8 +2436,10 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
             // (asked for behind it, a run of 64 KiB -- tiles 1 | 2 3 | 4 -- made a third trip)
             u32x4 odd[U > 1 ? U - 1 : 1];
 #pragma unroll
-            for (int u = 0; u < U - 1; ++u)
-                if (ntiles > u) odd[u] = load_tile(srd, voff, soff + u * kTileBytes);
+            for (int u = 0; u < U - 1; ++u) {
+                odd[u] = R.odd[u];
+                if (!R.early && ntiles > u) odd[u] = load_tile(srd, voff, soff + u * kTileBytes);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) horner_step(acc, cur[u], L);
 #pragma unroll
@@ -2395,50 +2453,71 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
             soff += kTileBytes;
             --ntiles;
         }
-
-        SIFT_PTRACE(2);
+        R.acc = acc;
+    };
+    uint32_t parity = 0;
+    // the run's residue: lane residue -> place in the tile -> XOR over the workgroup -> its record
+    auto reduce = [&](const Run& R) __attribute__((always_inline)) {
 #if SIFT_ABL == 1  // timing-only: no reduction, no verdict
-        if (acc[0] == 0x12345u && acc[1] == 7u) b.out[0] = 1u;
-        p += run;
-        continue;
+        if (R.acc[0] == 0x12345u && R.acc[1] == 7u) b.out[0] = 1u;
+        return;
 #endif
-        // Lane residue -> place in the tile -> XOR over the workgroup.
         uint32_t r = 0;
 #pragma unroll
-        for (int cw = 0; cw < 4; ++cw) r = ki_mul8<kTabX>(r ^ acc[cw], L);
+        for (int cw = 0; cw < 4; ++cw) r = ki_mul8<kTabX>(r ^ R.acc[cw], L);
         {
             uint32_t prod = 0;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) prod ^= kb[i] & (0u - ((r >> (31 - i)) & 1u));
+            for (int i = 0; i < 32; ++i) prod = xor_and(prod, kb[i], (uint32_t)((int32_t)(r << i) >> 31));
             r = prod;
         }
         r = wave_xor(r);
         uint32_t* redp = red + parity * kWaves;  // two sets: wave 0 may still be reading the other
+        parity ^= 1u;
         if ((tid & 63u) == 0) redp[tid >> 6] = r;
         __syncthreads();
         if (tid < 64u) {
             uint32_t x = wave_xor(tid < (uint32_t)kWaves ? redp[tid] : 0u);
             // weight x^(8 * 2^plog * k), k = pieces behind this one: the product of
             // x^(2^(3+plog+bit)) over the set bits of k (x^(2^s) has period 32 in s)
-            uint32_t k = np - 1u - jl;
+            uint32_t k = R.np - 1u - R.jl;
             for (uint32_t bit = 0; k; ++bit, k >>= 1)
-                if (k & 1u) x = mul_rows(x, ldsZ[((3u + plog + bit) & 31u) * 32u + row32], row32);
-            if (whole) {
+                if (k & 1u) x = mul_rows(x, ldsZ[((3u + R.plog + bit) & 31u) * 32u + row32], row32);
+            if (R.whole) {
                 if (tid == 0) {
-                    const CutRecord t = wide_record(slot);
-                    finish_record(b, &t, x, pre_tail, pre_stored);
+                    const CutRecord t = wide_record(R.slot);
+                    finish_record(b, &t, x, R.tail, R.stored);
                 }
-            } else if (slot == cur_slot) {  // into the record, through wave 0's commit pipeline
+            } else if (R.slot == cur_slot) {  // into the record, through wave 0's commit pipeline
                 cur_x ^= x;
-                cur_cnt += run;
+                cur_cnt += R.run;
             } else {
                 SIFT_COMMIT_ADVANCE();
-                cur_slot = slot;
+                cur_slot = R.slot;
                 cur_x = x;
-                cur_cnt = run;
+                cur_cnt = R.run;
             }
         }
-        p += run;
+    };
+    {
+        Run R, N;
+        bool have = false;
+        uint32_t slot = kVoidSlot;
+        bool more = locate(slot);
+        while (more || have) {
+            if (more) N = begin(slot);
+            if (have) {
+                SIFT_PTRACE(2);
+                reduce(R);
+            }
+            have = more;
+            if (more) {
+                stream(N);
+                R = N;
+                p += R.run;
+                more = locate(slot);
+            }
+        }
     }
     SIFT_PTRACE(3);
     if (PLAN == 1 && b.n == 1u) {
