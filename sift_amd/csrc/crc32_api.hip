@@ -1288,12 +1288,12 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // full is walked by its own wave instead (same bits, slower).
     bool cut = g_batch_cut.load() != 0;
     const int tuned_wave_max = g_batch_wave_max.load(), piece_log2 = g_batch_piece_log2.load();
-    // The longest span a wave keeps.  A wave alone streams 2.7 GB/s, so waves pay once there
+    // The longest span a wave keeps.  A wave alone streams 4 GB/s, so waves pay once there
     // are enough of them: measured crossover with the piece kernel (tools/cut_grid.sh,
-    // profiles/r03_cut_grid.txt) at 64 KiB for 2048 items, 128-256 KiB for 3000-4000.
+    // profiles/r03_cut_grid.txt) at 64 KiB for 1024 items, 128 KiB for 2048, 256 KiB for 3000-4000.
     const uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max
                               : n > 3072u        ? (256u << 10)
-                              : n > 2048u        ? (128u << 10)
+                              : n > 1536u        ? (128u << 10)
                               : n > 1024u        ? (64u << 10)
                                                  : (32u << 10);
     // Lengths the host can read (host or pinned arrays), not too many of them: if no
@@ -1506,7 +1506,11 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     while (per_wave < 64u && (uint64_t)per_wave * 2 * 4 * chip_waves <= n) per_wave *= 2;
     b.items_per_wave = per_wave;
     const uint64_t wave_chunks = ((uint64_t)n + per_wave - 1) / per_wave;
-    const int groups = (int)std::min<uint64_t>((wave_chunks + waves_per_group - 1) / waves_per_group,
+    // turns are dealt across the workgroups first (crc32_batch_kernel): a small batch spreads over the chip
+    // (descriptors read in place in pinned host memory: whole 64-byte lines a workgroup for a
+    // small batch, whole 128-byte lines -- what an XCD's L2 fetches -- for a large one)
+    b.deal_log2 = (w_off != Where::Device || w_len != Where::Device) && !use_inline ? (n <= 4096u ? 3u : 4u) : 0u;
+    const int groups = (int)std::min<uint64_t>((wave_chunks + (1u << b.deal_log2) - 1) >> b.deal_log2,
                                                (uint64_t)c->groups_max);
     launched = true;  // from here on a kernel may be queued even if a later step fails
     hipEvent_t e0 = nullptr, e1 = nullptr;  // measurement: pairs that ride on the dispatches

@@ -207,6 +207,7 @@ struct BatchArgs {
                           // 3: store the CRC field of serialized chunk i (Chunk::write), out[i] = status
     uint32_t chunk_limit; // verify: container.rs:49 size cap
     uint32_t items_per_wave;  // batch kernel: consecutive items a wave takes at a time, one per lane (1..64)
+    uint32_t deal_log2;       // ... and 2^deal_log2 consecutive turns stay on one workgroup (0..4)
     uint32_t* out;
     uint32_t* data_len;   // verify, optional: data length of each chunk that parsed
     const DeviceTables* tabs;

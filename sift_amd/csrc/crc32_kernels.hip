@@ -31,6 +31,9 @@
 #define SIFT_LOAD_AUX 2  // nt
 #endif
 #ifndef SIFT_KB_LOAD
+#ifndef SIFT_WAVE_BATCH
+#define SIFT_WAVE_BATCH 2  // tiles of 1 KiB a wave asks for at a time on a span of its own (wave_crc)
+#endif
 #define SIFT_KB_LOAD 0  // 1: the lane's 32 matrix rows come from a table instead of being computed (A/B: 2.5 us slower a call)
 #endif
 
@@ -832,25 +835,35 @@ __device__ __forceinline__ uint32_t wave_crc(const uint8_t* ptr, uint64_t len, u
         p += 64;
         --left;
     }
-    if (left >= 2) {
-        // two tiles in flight while the two before them are folded
-        u32x4 c0 = __builtin_nontemporal_load(p);
-        u32x4 c1 = __builtin_nontemporal_load(p + 64);
-        p += 128;
-        for (left -= 2; left >= 2; left -= 2) {
-            const u32x4 n0 = __builtin_nontemporal_load(p);
-            const u32x4 n1 = __builtin_nontemporal_load(p + 64);
-            p += 128;
-            horner_y(acc, c0);
-            horner_y(acc, c1);
-            c0 = n0;
-            c1 = n1;
+    constexpr int B = SIFT_WAVE_BATCH;  // tiles in flight while the B before them are folded
+    if (left >= B) {
+        u32x4 cc[B], nn[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) cc[u] = __builtin_nontemporal_load(p + 64 * u);
+        p += 64 * B;
+        for (left -= B; left >= B; left -= B) {
+#pragma unroll
+            for (int u = 0; u < B; ++u) nn[u] = __builtin_nontemporal_load(p + 64 * u);
+            p += 64 * B;
+#pragma unroll
+            for (int u = 0; u < B; ++u) horner_y(acc, cc[u]);
+#pragma unroll
+            for (int u = 0; u < B; ++u) cc[u] = nn[u];
         }
-        horner_y(acc, c0);
-        horner_y(acc, c1);
+        // the tiles behind the last whole batch are asked for before that batch is folded
+#pragma unroll
+        for (int u = 0; u < B - 1; ++u)
+            if (left > u) nn[u] = __builtin_nontemporal_load(p + 64 * u);
+#pragma unroll
+        for (int u = 0; u < B; ++u) horner_y(acc, cc[u]);
+#pragma unroll
+        for (int u = 0; u < B - 1; ++u)
+            if (left > u) horner_y(acc, nn[u]);
+        left = 0;
     }
-    if (left > 0) {
+    for (; left > 0; --left) {
         const u32x4 w = __builtin_nontemporal_load(p);
+        p += 64;
         horner_y(acc, w);
     }
     wave_request(np, nl, lane, nxt);
@@ -1572,8 +1585,16 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     if (b.cut.clear_flag && blockIdx.x == 0 && tid == 0) *b.cut.clear_flag = 0u;  // the next wide-plan call's flag
     __syncthreads();
 
+    // Turns of W items: turn q goes to workgroup q mod G, then to its wave (q / G) mod 16 --
+    // ACROSS the workgroups first.  (Consecutive turns on the waves of one workgroup put a
+    // batch of 1024 long items, one a wave, on 64 of the 256 CUs: 2.7 TB/s, bound by those
+    // CUs' vector issue.)
+    // Descriptors the GPU reads in place in pinned host memory: 2^deal_log2 = 8 consecutive
+    // turns stay on one workgroup (a 64-byte line of each array crosses PCIe once, not once
+    // per XCD that holds one of its turns).
     const uint32_t W = b.items_per_wave;
-    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (tid >> 6);
+    const uint32_t wv = tid >> 6, dl = b.deal_log2;
+    const uint64_t wave = ((((uint64_t)(wv >> dl) * gridDim.x + blockIdx.x) << dl) + (wv & ((1u << dl) - 1u)));
     const uint64_t step = (uint64_t)gridDim.x * kWaves * W;
     for (uint64_t first = wave * W; first < (uint64_t)b.n; first += step) {
         const bool have = lane < W && first + lane < (uint64_t)b.n;
