@@ -388,3 +388,22 @@ def test_wide_plan_chunks_vs_oracle(gpu, oracle, tune, count):
     st = container.write_chunk_crcs_device(d2, _dev([offs[i] for i in ok]), _dev([avail[i] for i in ok]))
     assert set(st.cpu().tolist()) == {0}
     assert bytes(d2.cpu().numpy()) == bytes(d.cpu().numpy())
+
+
+def test_wide_plan_one_huge_item_among_small(gpu):
+    # one item of 1.2 GiB (pieces of 2 MiB, runs capped at 1 GiB, many workgroups on one record)
+    # among 99 short ones and a few of 100..900 KiB: the wide plan's accumulators and its
+    # direct verdicts in one call; twice (the accumulators must be back at zero)
+    n_big = (1200 << 20) + 12345
+    g = torch.Generator(device="cuda").manual_seed(0x51F7 + 9)
+    d = torch.randint(0, 256, (n_big + (8 << 20),), dtype=torch.uint8, device="cuda", generator=g)
+    hb = d.cpu().numpy()
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.integers(0, 5000, size=99)] + [100_000, 333_333, 900_001, 65_537]
+    offs = [int(rng.integers(0, (8 << 20) - 1_000_000)) + n_big for _ in lens]
+    lens.insert(40, n_big)
+    offs.insert(40, 7)
+    want = [zlib.crc32(hb[o:o + n]) for o, n in zip(offs, lens)]
+    for rep in range(2):
+        got = gpu.compute_batch(M, d, _dev(offs), _dev(lens), xor_out=M).cpu().numpy().view(np.uint32)
+        assert [int(x) for x in got] == want, rep
