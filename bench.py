@@ -496,11 +496,10 @@ def secondary_batch(torch, sift_amd, pool) -> list:
                 "GBps_payload_over_kernel_time": round(payload / (sum(kus[1:]) * 1e-6) / 1e9, 1),
                 "roofline": _roof(names[dom], alg, kus[dom], launches[dom]), "checked": checked}
 
-    # -- many plain buffers: 1 Mi x 64 B and 1 Mi x 1 KiB, back to back in the pool
-    n = 1 << 20
-    out = torch.zeros(n, dtype=torch.int32, device=dev)
+    # -- many plain buffers: 1 Mi x 64 B, 1 Mi x 1 KiB and 1024 x 1 MiB, back to back in the pool
+    out = torch.zeros(1 << 20, dtype=torch.int32, device=dev)
     host = None
-    for size in (64, 1024):
+    for n, size in ((1 << 20, 64), (1 << 20, 1024), (1024, 1 << 20)):
         offs = torch.arange(n, dtype=torch.int64, device=dev) * size
         lens = torch.full((n,), size, dtype=torch.int64, device=dev)
 
@@ -511,7 +510,7 @@ def secondary_batch(torch, sift_amd, pool) -> list:
         pick = np.linspace(0, n - 1, 257).astype(np.int64)
         got = out[torch.from_numpy(pick).to(dev)].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         if host is None:
-            host = pool[: n * 1024].cpu().numpy()
+            host = pool[: 1 << 30].cpu().numpy()
         want = np.array([zlib.crc32(host[int(i) * size:(int(i) + 1) * size].tobytes()) for i in pick])
         assert (got == want).all(), f"batch {size} B: results differ from zlib"
         rows.append(row(f"crc32 of {n} buffers of {size} B (uniform random bytes), descriptors in HBM", "sift_crc32_batch_device",

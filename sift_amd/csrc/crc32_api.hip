@@ -1305,8 +1305,14 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
         for (uint32_t i = 0; i < n; ++i) longest = std::max(longest, lens[i]);
         if (longest <= wave_max) cut = false;  // a span is never longer than its item
     }
+    // Few items (and not the document mode, whose second chunk needs the wave
+    // kernel): no filing pass, the piece kernel plans for itself.
+    const bool plan = cut && n <= kPlanMax && verify != 2 && g_batch_plan.load() != 0;
+    // Up to kWideMax items (same exception): the batch kernel leaves the long spans alone and
+    // the piece kernel finds them itself -- no filing, no piece list.
+    const bool wide = cut && !plan && n <= kWideMax && verify != 2 && g_batch_plan.load() != 0;
     uint64_t extent = 1ull << 30;
-    if (cut) {
+    if (cut && !plan && !wide) {  // (the capacities below are the filed form's)
         hipDeviceptr_t abase = nullptr;
         size_t asize = 0;
         if (hipMemGetAddressRange(&abase, &asize, const_cast<void*>(d_base)) == hipSuccess && asize) {
@@ -1327,12 +1333,6 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // the device are not held up.
     StreamScratch& ss = *stream_scratch(c, st);
     std::lock_guard<std::mutex> lock(ss.m);
-    // Few items (and not the document mode, whose second chunk needs the wave
-    // kernel): no filing pass, the piece kernel plans for itself.
-    const bool plan = cut && n <= kPlanMax && verify != 2 && g_batch_plan.load() != 0;
-    // Up to kWideMax items (same exception): the batch kernel leaves the long spans alone and
-    // the piece kernel finds them itself -- no filing, no piece list.
-    const bool wide = cut && !plan && n <= kWideMax && verify != 2 && g_batch_plan.load() != 0;
     if (plan) {
         uint8_t* blk = nullptr;
         rc = stream_block_held(&ss, st, &blk);
