@@ -358,11 +358,6 @@ void build_tables(DeviceTables* t) {
     uint32_t p = kOne;
     for (int tdx = kThreads - 1; tdx >= 0; --tdx) {
         t->Kt[tdx] = p;
-        uint32_t r = p;
-        for (int i = 0; i < 32; ++i) {
-            t->KtRows[32 * tdx + i] = r;
-            r = gf2_mulx(r);
-        }
         p = gf2_mulmod(p, x128);
     }
 }

@@ -71,7 +71,6 @@ struct DeviceTables {
     uint32_t X[4 * 256];     // X[k*256+b] = (b << 8k) * x^32 mod P
     __attribute__((aligned(16))) uint32_t Xt[256 * 4];  // Xt[4b + k] = X[k*256+b]
     uint32_t Kt[kThreads];   // Kt[t] = x^(128 * (kThreads-1-t)) mod P
-    __attribute__((aligned(16))) uint32_t KtRows[kThreads * 32];  // KtRows[32t + i] = Kt[t] * x^i: lane t's multiplication matrix
     uint32_t Y1[4 * 256];    // Y1[k*256+b] = (b << 8k) * x^(8*1024) mod P  (one-wave tiles, batch kernel)
     uint32_t Y256[4 * 256];  // Y256[k*256+b] = (b << 8k) * x^(8*256) mod P  (a chain of a lane group steps over 16 vectors, batch kernel)
     uint32_t T8[256];        // T8[b] = b * x^8 mod P: the reference's CRC_TABLE itself (crc.rs:2-20), for

@@ -12,11 +12,18 @@
 // crc32_tiles_kernel   one buffer, whole chip.  Each workgroup owns a
 //     contiguous run of 16 KiB tiles and folds it to one 32-bit residue.
 //     HBM-bound by design: one coalesced, non-temporal dwordx4 load per lane
-//     per tile, 16 LDS lookups and ~50 VALU ops per load.  The tables sit in
-//     LDS replicated once per bank so that a lookup with 32 different indices
-//     in a half-wave is conflict-free.  The workgroups exchange residues
-//     through two 64-bit atomics; the last to arrive finishes (single launch).
-// crc32_batch_kernel   many buffers, one wave per buffer (also Chunk::read x n).
+//     per tile, 16 LDS lookups and ~25 VALU ops per load.  The tables sit in
+//     LDS in rows by byte value (KiLane): 8 copies are conflict-free and a
+//     lookup's address is one v_perm_b32.  The workgroups exchange residues
+//     through one returning 64-bit atomic per level; the last to arrive
+//     finishes (single launch).
+// crc32_batch_kernel   many buffers (also Chunk::read / Chunk::write's crc step /
+//     read_document's framing x n): a wave takes 64 items a turn, one lane per
+//     item for parsing and verdict; the CRC spans by one lane, a group of 2 / 4 / 8
+//     lanes or the whole wave, by length.  Longer spans go to
+// crc32_pieces_kernel  the tile kernel's algorithm over pieces of long items:
+//     planned by the kernel itself for up to 4096 items, filed by the batch
+//     kernel's waves beyond.
 // crc32_combine_kernel inputs under 32 bytes (one lane), and the second launch
 //     of the two-launch A/B form (tree over the <= 1024 residues).
 #include <hip/hip_runtime.h>
@@ -30,11 +37,8 @@
 #ifndef SIFT_LOAD_AUX
 #define SIFT_LOAD_AUX 2  // nt
 #endif
-#ifndef SIFT_KB_LOAD
 #ifndef SIFT_WAVE_BATCH
-#define SIFT_WAVE_BATCH 2  // tiles of 1 KiB a wave asks for at a time on a span of its own (wave_crc)
-#endif
-#define SIFT_KB_LOAD 0  // 1: the lane's 32 matrix rows come from a table instead of being computed (A/B: 2.5 us slower a call)
+#define SIFT_WAVE_BATCH 2  // tiles of 1 KiB a wave asks for at a time on a span of its own (wave_crc; 3 and 4: no faster)
 #endif
 
 namespace sift {
@@ -365,9 +369,7 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         tx[k] = stage_fetch(a.tabs->Xt, i < (uint32_t)kStagePairs ? i : 0u);
     }
     uint32_t kb[32];
-#if !SIFT_KB_LOAD
     kb[0] = a.tabs->Kt[tid];
-#endif
     // the block the trailing bytes lie in (16-byte aligned, inside the page of the last
     // byte), for whichever group turns out to finish the call
     const u32x4 tailv = *reinterpret_cast<const u32x4*>(f.tail_len ? f.tail : reinterpret_cast<const uint8_t*>(a.vbase));
@@ -420,23 +422,6 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
         soff += U * kTileBytes;
         ntiles -= U;
     }
-#if SIFT_KB_LOAD
-    // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its multiplication
-    // matrix (3 instructions a bit at the end instead of 7): asked for BEHIND the first
-    // message vectors -- they are not needed before the end of the call -- from a table of
-    // all 1024 x 32 rows.  (Until round 3 each lane computed its rows from Kt[tid] in the
-    // prologue: 124 dependent instructions a lane, 0.8 us of a CU's vector issue while the
-    // tables wait to be staged.)
-    {
-        const u32x4* rows = reinterpret_cast<const u32x4*>(a.tabs->KtRows) + tid * 8u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const u32x4 v = rows[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kb[4 * i + j] = v[j];
-        }
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 
     // Tables -> LDS.
@@ -455,13 +440,12 @@ __global__ __launch_bounds__(kThreads) void crc32_tiles_kernel(TileArgs a, Final
     // This lane's place in the tile, Kt[tid], as the 32 rows kt * x^i of its
     // multiplication matrix: computed here, while the first loads are in flight
     // and the VALU is idle, and kept in registers through the main loop, so that
-    // the multiply at the end is 3 instructions per bit instead of 7.
-#if !SIFT_KB_LOAD
+    // the multiply at the end is 2 instructions per bit instead of 7.  (The rows loaded from
+    // a 1024 x 32 table instead: 2.5 us slower a call, eight more loads a lane in the memory pipe.)
 #pragma unroll
     for (int i = 1; i < 32; ++i) kb[i] = gf2_mulx(kb[i - 1]);
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(kb[i]));  // pin: do not sink past the loop
-#endif
     __syncthreads();
     SIFT_TRACE(1);
 
@@ -1799,9 +1783,10 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
 }
 
 // ---------------------------------------------------------------------------
-// Piece kernel: the pieces the batch kernel filed, one workgroup per piece, with
-// the tile kernel's algorithm (16 KiB tiles, stride-one-tile Horner, y table
-// replicated per bank).  Piece j of a record covers
+// Piece kernel: the pieces of the long items (planned by the kernel itself, or filed by
+// the batch kernel: see the PLAN forms below), a workgroup per run of pieces, with
+// the tile kernel's algorithm (16 KiB tiles, stride-one-tile Horner, y table in
+// rows by byte value).  Piece j of a record covers
 //     [Eb - (np-j)*P, Eb - (np-1-j)*P),   Eb = end of the span rounded down to 16,
 // piece 0 starting at the span's first byte instead; its residue is weighted by
 // x^(8*P*(np-1-j)), so that the XOR of a record's residues is the register at Eb.
