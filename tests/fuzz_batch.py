@@ -31,7 +31,8 @@ def pick_size(rng):
 
 def one_round(seed):
     rng = np.random.default_rng(seed)
-    n = int([1, 2, 7, 63, 64, 65, 200, 1000, 4096, 4097, 6000][int(rng.integers(0, 11))])
+    counts = [1, 2, 7, 63, 64, 65, 200, 1000, 1024, 1025, 1536, 1537, 3072, 3073, 4096, 4097, 6000]
+    n = int(counts[int(rng.integers(0, len(counts)))])
     budget = 48 << 20
     stream = bytearray()
     offs, avail, want = [], [], []
@@ -67,6 +68,22 @@ def one_round(seed):
         assert status[i] == want[i][0], (seed, "docs" if docs else "chunks", n, where, i, status[i], want[i], avail[i])
         if want[i][1] is not None:
             assert dlen[i] == want[i][1], (seed, n, where, i, dlen[i], want[i])
+    # Chunk::write's crc step (container.rs:75) on the chunks that read clean: their crc
+    # fields zeroed, filled in again by the device, the stream must be what it was
+    if not docs:
+        clean = [i for i in range(n) if status[i] == 0]
+        if clean:
+            d2 = d.clone()
+            for i in clean:
+                at = offs[i] + 8 + want[i][1]
+                d2[at:at + 4] = 0
+            co = [offs[i] for i in clean]
+            ca = [avail[i] for i in clean]
+            st3 = container.write_chunk_crcs_device(
+                d2, torch.tensor(co, dtype=torch.int64, device="cuda") if where else co,
+                torch.tensor(ca, dtype=torch.int64, device="cuda") if where else ca)
+            assert set(st3.cpu().tolist()) == {0}, (seed, "write status", n, where)
+            assert bool((d2 == d).all().item()), (seed, "write bytes", n, where)
     # plain buffers over the same bytes
     lens = [min(av, int(rng.integers(0, av + 1)) if rng.random() < 0.5 else av) for av in avail]
     got = crc.compute_batch(0xFFFFFFFF, d, o if where else offs,
