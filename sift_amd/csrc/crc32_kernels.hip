@@ -1955,9 +1955,9 @@ __device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, const uint64_
 // of the piece kernel now finds those for itself, identically: lane t takes items 4t .. 4t+3
 // (descriptors asked for at the top of the kernel), repeats the checks that come before the
 // CRC, and counts the pieces of the spans over wave_max -- the batch kernel's own test
-// (crc_spans).  wide_end[i] = pieces of items 0 .. i (a scan over the workgroup); dlen[i] =
-// data length of chunk i (chunk modes).  Nothing is filed and no word of device memory is
-// written: a run finds its item by two 64-way looks into wide_end, and the item's span in
+// (crc_spans).  wide_end[i] = pieces of items 0 .. i (a scan over the workgroup).  Nothing
+// is filed and no word of device memory is written: a run finds its item by two 64-way
+// looks into wide_end, and the item's span in
 // spans[2i], spans[2i+1] (offset, length) -- a run of 64 KiB lasts 2.4 us at the workgroup's
 // share of the memory system, and a descriptor read again from memory was a third trip
 // in front of it.  Returns the piece total.
