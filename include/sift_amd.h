@@ -122,9 +122,10 @@ enum {
     SIFT_TUNE_BATCH_CUT = 2,     /* 1 (default): the batch entry points cut long items on the
                                     device; 0: one wave per item whatever its length */
     SIFT_TUNE_BATCH_WAVE_MAX = 3,/* bytes of CRC span one wave keeps before the item is cut;
-                                    0 (default) = by item count: 32 KiB up to 1024 items, 64 KiB up
-                                    to 1536, 128 KiB up to 3072, 256 KiB beyond (a wave alone
-                                    streams 4 GB/s: waves pay once there are thousands) */
+                                    0 (default) = from the items' lengths: 32 KiB, or 64 / 128 /
+                                    256 KiB when a sample of the batch holds thousands of items
+                                    that long (a wave alone streams 4.5 GB/s: waves pay once there
+                                    are thousands; a lone long item is always cut) */
     SIFT_TUNE_BATCH_PIECE_LOG2 = 4, /* log2 of the smallest piece, 14..24 (default 16 = 64 KiB) */
     SIFT_TUNE_HOST_COPY_THREADS = 6, /* helper threads that fill the pinned bounce ring for pageable
                                     input of more than 512 KiB, 1..16 (default 4; the calling thread
@@ -247,7 +248,7 @@ int sift_chunk_crc_device(int device, const void *d_type_and_data, uint64_t data
  * Short items are taken 64 at a time by a wave (one lane per item for parsing,
  * checks and the verdict; the CRC itself by one lane, a group of 4 or 8 lanes or the
  * whole wave, by length).  An item whose CRC span is long
- * (over 32 KiB for up to 1024 items, rising to 256 KiB beyond 3072) is cut ON THE DEVICE --
+ * (over 32 KiB; over 64 / 128 / 256 KiB when the batch holds thousands that long) is cut ON THE DEVICE --
  * in the chunk modes the length is only in the chunk's header -- into pieces of
  * 64 KiB and up that whole workgroups reduce, so one 1 GiB chunk, 64 chunks of
  * 16 MiB and a million 64-byte chunks all run near the memory rate, whether the

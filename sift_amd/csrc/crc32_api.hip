@@ -1283,18 +1283,20 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
     // full is walked by its own wave instead (same bits, slower).
     bool cut = g_batch_cut.load() != 0;
     const int tuned_wave_max = g_batch_wave_max.load(), piece_log2 = g_batch_piece_log2.load();
-    // The longest span a wave keeps.  A wave alone streams 4 GB/s, so waves pay once there
-    // are enough of them: measured crossover with the piece kernel (tools/cut_grid.sh,
-    // profiles/r03_cut_grid.txt) at 64 KiB for 1024 items, 128 KiB for 2048, 256 KiB for 3000-4000.
-    const uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max
-                              : n > 3072u        ? (256u << 10)
-                              : n > 1536u        ? (128u << 10)
-                              : n > 1024u        ? (64u << 10)
-                                                 : (32u << 10);
+    // The longest span a wave keeps: from the lengths themselves (crc32_device.h, wave_max_of),
+    // here if the host can read them, else by the kernels.
+    const bool host_lens = w_len != Where::Device;
+    const uint32_t sample_stride = wave_sample_stride(n);
+    const bool wave_adapt = tuned_wave_max <= 0 && !host_lens;
+    uint32_t wave_max = tuned_wave_max > 0 ? (uint32_t)tuned_wave_max : kWaveMin;
+    if (tuned_wave_max <= 0 && host_lens && n) {
+        uint32_t cls[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < std::min(n, kWaveSample); ++k) ++cls[wave_class(lens[wave_sample_item(k, n)])];
+        wave_max = wave_max_of(cls[1], cls[2], cls[3], sample_stride);
+    }
     // Lengths the host can read (host or pinned arrays), not too many of them: if no
     // item can hold a span longer than wave_max, nothing will be filed and the call is
     // the wave kernel alone -- no scratch, no second launch (6 us of an otherwise 8 us call).
-    const bool host_lens = w_len != Where::Device;
     if (cut && host_lens && n > kPlanMax && n <= 4096u) {
         uint64_t longest = 0;
         for (uint32_t i = 0; i < n; ++i) longest = std::max(longest, lens[i]);
@@ -1316,7 +1318,11 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
             (void)hipGetLastError();
         }
     }
-    const uint64_t cap_recs = std::min<uint64_t>(n, extent / wave_max + 1);
+    // (filed spans are longer than the threshold, at least kWaveMin when the kernels work it out;
+    // at most a million records unless the threshold itself allows more)
+    const uint64_t cap_recs =
+        std::min<uint64_t>({(uint64_t)n, extent / (wave_adapt ? kWaveMin : wave_max) + 1,
+                            std::max<uint64_t>(extent / (256u << 10) + 1, 1u << 20)});
     const uint64_t cap_pieces = std::min<uint64_t>((extent >> piece_log2) + cap_recs + 1, 0x7FFFFFFFull);
     hipStream_t st = stream;
     if (capturing(st)) {
@@ -1375,6 +1381,7 @@ int run_batch(int device, const void* d_base, const uint64_t* offsets, const uin
             b.cut.cap_pieces = (uint32_t)cap_pieces;
         }
         b.cut.wave_max = wave_max;
+        b.cut.wave_adapt = wave_adapt ? 1u : 0u;
         b.cut.piece_min_log2 = (uint32_t)piece_log2;
     }
     // Few items with descriptors the host can read: they go into the kernel arguments.

@@ -148,6 +148,38 @@ constexpr uint32_t kPlanMax = 64;             // up to this many items the piece
 constexpr uint32_t kWideMax = 4096;           // up to this many it plans the LONG ones (four items a lane, all lanes), the
                                               // batch kernel keeps the others: no filing (one returning atomic pair per long
                                               // item on two words: 23 ns an item, 25 us of a 190 us call on 1024 x 1 MiB)
+// The longest span a wave keeps (wave_max), from the lengths themselves.  A wave alone streams
+// about 4.5 GB/s, whole workgroups 27 GB/s each but at 2 us a run: waves pay when there are
+// thousands of spans of a length, pieces when there are few (profiles/r03_cut_grid.json:
+// crossover near 1100 items at 64 KiB, 1500-2000 at 128 KiB, 2500-3500 at 256 KiB).  The item
+// COUNT says nothing about that: 3500 items of 64 bytes and one of 250 KiB took 62 us with
+// the 250 KiB on one wave, 18 us with it cut.  So lengths are counted in three classes
+// (32-64, 64-128, 128-256 KiB) over a sample of kWaveSample items -- four runs of 64 at the
+// quarter points of the batch, which every wave reads and counts for itself (ballots; the
+// same 2 KiB for all of them) -- and the threshold is the top of the highest class with
+// enough members.  Same function on the host (lengths it can read) and in both kernels
+// (lengths in HBM).  (A sample of 4096 evenly spaced items counted by the workgroup together
+// cost a million-item call 5 us, 1024 still 2.5, the workgroup's barriers alone 2 -- and a
+// batch of a hundred items 3.7.)
+constexpr uint32_t kWaveSample = 256;
+constexpr uint32_t kWaveMin = 32u << 10;
+// what one sample member stands for, and member k's item (k < n, k < kWaveSample)
+__host__ __device__ inline uint32_t wave_sample_stride(uint32_t n) {
+    return n <= kWaveSample ? 1u : n / kWaveSample;
+}
+__host__ __device__ inline uint32_t wave_sample_item(uint32_t k, uint32_t n) {
+    return n <= kWaveSample ? k : (n / 4u) * (k >> 6) + (k & 63u);
+}
+__host__ __device__ inline uint32_t wave_class(uint64_t len) {  // 0: none, 1..3
+    return len <= (32u << 10) || len > (256u << 10) ? 0u : len <= (64u << 10) ? 1u : len <= (128u << 10) ? 2u : 3u;
+}
+__host__ __device__ inline uint32_t wave_max_of(uint32_t c1, uint32_t c2, uint32_t c3, uint32_t stride) {
+    uint32_t t = kWaveMin;  // counts are of the sample: times the stride for the batch
+    if ((uint64_t)c1 * stride >= 1100u) t = 64u << 10;
+    if ((uint64_t)c2 * stride >= 1500u) t = 128u << 10;
+    if ((uint64_t)c3 * stride >= 2500u) t = 256u << 10;
+    return t;
+}
 constexpr uint32_t kVoidSlot = 0xFFFFFFFFu;  // piece_rec entry of a reservation that did not fit           // pieces of at most 1 GiB (32-bit buffer offsets)
 
 struct CutRecord {
@@ -176,6 +208,9 @@ struct CutArgs {
     uint32_t* piece_rec;         // piece -> record slot, or kVoidSlot
     uint32_t cap_recs, cap_pieces;
     uint32_t wave_max;           // spans of up to this many bytes stay on the wave that found them
+    // wave_adapt: wave_max is worked out by the kernels from the items' lengths (wave_threshold:
+    // every wave of both kernels, identically), because the host cannot read them
+    uint32_t wave_adapt;
     uint32_t piece_min_log2;     // smallest piece, log2 bytes (kPieceMinLog2 unless tuned)
     // Wide plan (64 < n <= kWideMax): a wave that meets a long span leaves it alone and raises
     // *long_flag; the piece kernel returns at once when it is not raised.  Two flag words take

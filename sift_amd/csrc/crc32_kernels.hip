@@ -1406,6 +1406,27 @@ static_assert(kGroup4Max >= 128 && kGroup4Max <= 256, "4-lane groups take one ro
 constexpr uint32_t kEndFramedMax = SIFT_END_FRAMED_MAX;  // ... that is framed from the spans' ends
 static_assert(kEndFramedMax >= kGroup4Max, "4-lane groups are framed from the end");
 
+// wave_max from the lengths (crc32_device.h, wave_max_of): lane l of EVERY wave looks at
+// sample members l, l + 64, l + 128, l + 192 (wave_sample asks for them early), and the wave
+// counts their classes by ballot.
+__device__ __forceinline__ void wave_sample(const BatchArgs& b, uint64_t (&len4)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = (threadIdx.x & 63u) + 64u * (uint32_t)k;
+        len4[k] = m < b.n && m < kWaveSample ? b.lens[wave_sample_item(m, b.n)] : 0ull;
+    }
+}
+__device__ __forceinline__ uint32_t wave_threshold(const BatchArgs& b, const uint64_t (&len4)[4]) {
+    uint32_t cnt[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cl = wave_class(len4[k]);  // (a member the batch does not have has length 0: no class)
+#pragma unroll
+        for (uint32_t q = 0; q < 3u; ++q) cnt[q] += (uint32_t)__builtin_popcountll(__ballot(cl == q + 1u));
+    }
+    return wave_max_of(cnt[0], cnt[1], cnt[2], wave_sample_stride(b.n));
+}
+
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
 }
@@ -1553,12 +1574,14 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     __shared__ __align__(16) uint32_t lds[kBatchLdsWords];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    uint64_t len4[4] = {0, 0, 0, 0};
     {
         const u32x4* img = reinterpret_cast<const u32x4*>(b.tabs->batch_image);
         static_assert(kBatchLdsWords % (4 * kThreads) == 0, "whole rounds of 16-byte copies");
         u32x4 t[kBatchLdsWords / (4 * kThreads)];
 #pragma unroll
         for (int r = 0; r < kBatchLdsWords / (4 * kThreads); ++r) t[r] = img[tid + (uint32_t)(r * kThreads)];
+        if (b.cut.wave_adapt) wave_sample(b, len4);  // asked for behind the tables, looked at behind the barrier
 #pragma unroll
         for (int r = 0; r < kBatchLdsWords / (4 * kThreads); ++r)
             reinterpret_cast<u32x4*>(lds)[tid + (uint32_t)(r * kThreads)] = t[r];
@@ -1568,6 +1591,7 @@ __global__ __launch_bounds__(kThreads) void crc32_batch_kernel(BatchArgs b) {
     const KiLane L = ki_lane(lane);
     if (b.cut.clear_flag && blockIdx.x == 0 && tid == 0) *b.cut.clear_flag = 0u;  // the next wide-plan call's flag
     __syncthreads();
+    if (b.cut.wave_adapt) b.cut.wave_max = wave_threshold(b, len4);
 
     // Turns of W items: turn q goes to workgroup q mod G, then to its wave (q / G) mod 16 --
     // ACROSS the workgroups first.  (Consecutive turns on the waves of one workgroup put a
@@ -1961,10 +1985,11 @@ __device__ __forceinline__ uint32_t plan_items(const BatchArgs& b, const uint64_
 // spans[2i], spans[2i+1] (offset, length) -- a run of 64 KiB lasts 2.4 us at the workgroup's
 // share of the memory system, and a descriptor read again from memory was a third trip
 // in front of it.  Returns the piece total.
-__device__ __forceinline__ uint32_t plan_wide(const BatchArgs& b, const uint64_t (&d_off)[4],
-                                              const uint64_t (&d_avail)[4], uint32_t* wide_end, uint64_t* spans,
-                                              uint32_t* parts) {
+__device__ __forceinline__ uint32_t plan_wide(BatchArgs& b, const uint64_t (&d_off)[4],
+                                              const uint64_t (&d_avail)[4], const uint64_t (&sample4)[4],
+                                              uint32_t* wide_end, uint64_t* spans, uint32_t* parts) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (b.cut.wave_adapt) b.cut.wave_max = wave_threshold(b, sample4);  // the threshold the batch kernel worked out
     uint32_t np[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2094,7 +2119,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
     // behind them -- are on their way (round 2 staged after the plan: two trips to memory
     // with idle lanes, then 0.8 us of vector work with an idle memory system).
     uint64_t d_off = 0, d_avail = 0;
-    uint64_t w_off[4] = {0, 0, 0, 0}, w_avail[4] = {0, 0, 0, 0};
+    uint64_t w_off[4] = {0, 0, 0, 0}, w_avail[4] = {0, 0, 0, 0}, w_sample[4] = {0, 0, 0, 0};
     unsigned long long reserved = 0;
     if (PLAN == 1) {
         const uint64_t* inl = nullptr;
@@ -2111,6 +2136,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
             w_off[k] = b.offsets[i < b.n ? i : 0u];
             w_avail[k] = b.lens[i < b.n ? i : 0u];
         }
+        if (b.cut.wave_adapt) wave_sample(b, w_sample);
     } else {
         reserved = *c.pieces;
     }
@@ -2181,7 +2207,7 @@ __global__ __launch_bounds__(kThreads) void crc32_pieces_kernel(BatchArgs b,
         // (ends with the workgroup's barrier, which also covers the tables staged above)
         total = plan_items(b, inl, prec, plan_pbase, plan_pbase + kPlanMax, d_off, d_avail, pre_tail, pre_stored);
     } else if (PLAN == 2) {
-        total = plan_wide(b, w_off, w_avail, wide_end, wide_span, wide_parts);  // (ends with a barrier too)
+        total = plan_wide(b, w_off, w_avail, w_sample, wide_end, wide_span, wide_parts);  // (ends with a barrier too)
     } else {
         __syncthreads();
     }

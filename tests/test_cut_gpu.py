@@ -407,3 +407,25 @@ def test_wide_plan_one_huge_item_among_small(gpu):
     for rep in range(2):
         got = gpu.compute_batch(M, d, _dev(offs), _dev(lens), xor_out=M).cpu().numpy().view(np.uint32)
         assert [int(x) for x in got] == want, rep
+
+
+@pytest.mark.parametrize("count,size", [(2048, 65536 + 17), (300, 65536 + 17), (2600, 101_000), (5000, 40_000)])
+def test_wave_threshold_from_the_lengths(gpu, count, size):
+    # The span length above which an item is cut comes from the lengths themselves (a sample
+    # every wave of both kernels counts alike; on the host when it can read them): thousands
+    # of like items stay on waves, few are cut, and a lone long item among them is cut
+    # whatever the count.  Same bits every way, descriptors in HBM and on the host.
+    rng = np.random.default_rng(count)
+    blob = rng.integers(0, 256, size=(160 << 20) + 4096, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    hb = blob.tobytes()
+    lens = [size - int(x) for x in rng.integers(0, 9, size=count)]
+    lens[count // 3] = 250_000          # a lone longer one
+    lens[count // 2] = (3 << 20) + 5    # and a much longer one
+    lens[5] = 40
+    offs = [int(rng.integers(0, blob.size - n + 1)) for n in lens]
+    want = [zlib.crc32(hb[o:o + n]) for o, n in zip(offs, lens)]
+    for off_arg, len_arg in ((_dev(offs), _dev(lens)), (offs, lens)):
+        got = gpu.compute_batch(M, d, off_arg, len_arg, xor_out=M).cpu().numpy().view(np.uint32)
+        bad = [i for i, w in enumerate(want) if int(got[i]) != w]
+        assert not bad, (count, size, bad[:5])
