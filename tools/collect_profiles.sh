@@ -24,5 +24,6 @@ timeout -k 10 200 python tools/async_sweep.py > gpurun_out/${RND}_async_sweep.js
 SIFT_AMD_LIB=$R/tools/bin/trace/libsift_amd.so timeout -k 10 120 python tools/trace_groups.py > gpurun_out/${RND}_group_trace.txt
 bash tools/collect_midsize.sh ${RND}
 bash tools/cut_grid.sh > gpurun_out/${RND}_cut_grid.json
+timeout -k 10 300 python tools/lone_long_item.py > gpurun_out/${RND}_lone_long_item.txt
 bash tools/collect_batch_pmc.sh ${RND}
 echo collected

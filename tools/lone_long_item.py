@@ -1,5 +1,11 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+"""One long item among many short ones: device time per call of the batch entry point for n
+items of 64 bytes, alone and with ONE item of 100 KiB / 250 KiB / 2 MiB among them (descriptors
+in HBM, through the Python binding: about 11 us of every figure is the binding).  The long
+item must cost what its bytes cost, whatever n is (round 3: with the cut threshold chosen
+from n alone, 3500 items + one of 250 KiB took 62 us)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sift_amd
 from sift_amd import crc
 dev = torch.device('cuda:0')

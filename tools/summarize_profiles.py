@@ -188,7 +188,8 @@ import shutil
 
 for src, dst in ((f"bench_{rnd}.json", f"{rnd}_bench.json"), (f"{rnd}_batch_bench.json", f"{rnd}_batch_bench.json"),
                  (f"{rnd}_size_sweep.json", f"{rnd}_size_sweep.json"), (f"{rnd}_async_sweep.json", f"{rnd}_async_sweep.json"),
-                 (f"{rnd}_group_trace.txt", f"{rnd}_group_trace.txt"), (f"{rnd}_cut_grid.json", f"{rnd}_cut_grid.json")):
+                 (f"{rnd}_group_trace.txt", f"{rnd}_group_trace.txt"), (f"{rnd}_cut_grid.json", f"{rnd}_cut_grid.json"),
+                 (f"{rnd}_lone_long_item.txt", f"{rnd}_lone_long_item.txt")):
     if os.path.exists(os.path.join(GO, src)):
         shutil.copyfile(os.path.join(GO, src), os.path.join(PR, dst))
 hits = glob.glob(os.path.join(GO, f"{rnd}_batch_trace/*/*kernel_stats.csv"))
